@@ -1,0 +1,31 @@
+# Builds librenderbaby_hip.so (HIP kernels for gfx950 + C-ABI runtime) and the
+# CPU oracle.  Explicit hipcc; no cmake, no JIT cache -- the .so stays in-tree so
+# it travels to the GPU box.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := renderbaby_amd/csrc
+OUT      := renderbaby_amd/librenderbaby_hip.so
+# Numerics contract: no FMA contraction, correctly rounded / and sqrt, no fast-math.
+NUMERICS := -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -Wall -Wno-unused-function
+SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp
+HDRS     := $(CSRC)/rb_internal.hpp include/rb_abi.h
+
+all: $(OUT) oracle
+
+$(OUT): $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle
+
+asm: $(CSRC)/rb_kernels.hip $(HDRS)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/rb_kernels.s $(CSRC)/rb_kernels.hip \
+	    -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
+
+clean:
+	rm -f $(OUT) build/*.s build/*.txt
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle asm clean

@@ -1,0 +1,386 @@
+/*
+ * rb_abi.h -- C ABI of librenderbaby_hip.so, the MI355X (gfx950) backend for
+ * RenderBaby's path-tracing hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what a Rust shim
+ * crate (`engine-hip`) binds with `extern "C"` to implement
+ * `engine_config::Renderer` and `frame_buffer::FrameIterator`.  All citations
+ * are file:line under the reference checkout (crates/... , src/...).
+ *
+ * Plain C: pointers, sizes, PODs.  No torch, no C++ types.  Inputs are borrowed
+ * for the duration of a call only (copied to the device before return); the
+ * library owns every device allocation; outputs go to caller-owned buffers.
+ */
+#ifndef RB_ABI_H
+#define RB_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* POD layouts -- byte-identical to the reference's #[repr(C)] GPU ABI types */
+/* ------------------------------------------------------------------------ */
+
+/* crates/engine-config/src/camera.rs:27-61 (48 B) */
+typedef struct rb_camera {
+    float pane_distance;
+    float pane_width;
+    float _pad0[2];
+    float pos[3];
+    float _pad1;
+    float dir[3];
+    float _pad2;
+} rb_camera;
+
+/* crates/engine-config/src/uniforms.rs:26-67 (144 B) */
+typedef struct rb_uniforms {
+    uint32_t width;
+    uint32_t height;
+    uint32_t total_samples;
+    uint32_t color_hash_enabled;
+    rb_camera camera;
+    uint32_t spheres_count;
+    uint32_t triangles_count;
+    uint32_t bvh_node_count;
+    uint32_t bvh_triangle_count;
+    uint32_t bvh_root;
+    float ground_height;
+    uint32_t ground_enabled;
+    uint32_t checkerboard_enabled;
+    float sky_color[3];
+    uint32_t max_depth;
+    float checkerboard_color_1[3];
+    uint32_t _pad1;
+    float checkerboard_color_2[3];
+    uint32_t _pad2;
+} rb_uniforms;
+
+/* crates/engine-config/src/material.rs:34-65 (80 B) */
+typedef struct rb_material {
+    float ambient[3];
+    float _pad0;
+    float diffuse[3];
+    float _pad1;
+    float specular[3];
+    float shininess;
+    float emissive[3];
+    float ior;
+    float opacity;
+    uint32_t illum;
+    int32_t texture_index;
+    uint32_t _pad2;
+} rb_material;
+
+/* crates/engine-config/src/sphere.rs:34-43 (96 B) */
+typedef struct rb_sphere {
+    float center[3];
+    float radius;
+    rb_material material;
+} rb_sphere;
+
+/* crates/engine-config/src/point_lights.rs:23-33 (96 B) */
+typedef struct rb_point_light {
+    float center[3];
+    float radius;
+    rb_material material;
+} rb_point_light;
+
+/* crates/engine-config/src/mesh.rs:21-32 (96 B) */
+typedef struct rb_mesh {
+    uint32_t triangle_index_start;
+    uint32_t triangle_count;
+    uint32_t _pad[2];
+    rb_material material;
+} rb_mesh;
+
+/* crates/engine-bvh/src/bvh.rs:18-34 (48 B) */
+typedef struct rb_bvh_node {
+    float aabb_min[3];
+    uint32_t _pad0;
+    float aabb_max[3];
+    uint32_t _pad1;
+    uint32_t left;
+    uint32_t right;
+    uint32_t first_primitive;
+    uint32_t primitive_count;
+} rb_bvh_node;
+
+/* crates/engine-bvh/src/triangle.rs:9-29 (64 B) */
+typedef struct rb_gpu_triangle {
+    float v0[3];
+    uint32_t v0_index;
+    float v1[3];
+    uint32_t v1_index;
+    float v2[3];
+    uint32_t v2_index;
+    uint32_t mesh_index;
+    uint32_t _pad0;
+    uint32_t _pad1;
+    uint32_t _pad2;
+} rb_gpu_triangle;
+
+/* crates/engine-config/src/texture.rs:26-36 -- Vec<u32> becomes ptr + w*h */
+typedef struct rb_texture {
+    uint32_t width;
+    uint32_t height;
+    const uint32_t* rgba_data; /* width*height texels, R in the low byte */
+} rb_texture;
+
+/* crates/engine-wgpu-wrapper/src/buffers.rs:13-25 (16 B); offset is in texels
+ * (buffers.rs:151-168) */
+typedef struct rb_texture_info {
+    uint32_t offset;
+    uint32_t width;
+    uint32_t height;
+    uint32_t _pad;
+} rb_texture_info;
+
+/* crates/engine-wgpu-wrapper/src/gpu_wrapper.rs:19-31 (16 B) */
+typedef struct rb_progressive {
+    uint32_t total_passes;
+    uint32_t current_pass;
+    uint32_t total_samples;
+    uint32_t samples_per_pass;
+} rb_progressive;
+
+/* ------------------------------------------------------------------------ */
+/* RenderConfig = 9 x Change<T>  (crates/engine-config/src/render_config.rs:37-57,99-109) */
+/* ------------------------------------------------------------------------ */
+
+enum {
+    RB_KEEP = 0,   /* Change::Keep   */
+    RB_CREATE = 1, /* Change::Create */
+    RB_UPDATE = 2, /* Change::Update */
+    RB_DELETE = 3  /* Change::Delete */
+};
+
+typedef struct rb_field {
+    uint32_t change;  /* RB_KEEP.. */
+    const void* ptr;  /* element array (may be NULL when count == 0) */
+    size_t count;     /* number of ELEMENTS (uvs: number of f32) */
+} rb_field;
+
+typedef struct rb_config {
+    rb_field uniforms;      /* 1 x rb_uniforms */
+    rb_field spheres;       /* rb_sphere[] */
+    rb_field uvs;           /* float[] (pairs) */
+    rb_field meshes;        /* rb_mesh[] */
+    rb_field lights;        /* rb_point_light[] */
+    rb_field bvh_nodes;     /* rb_bvh_node[] */
+    rb_field bvh_indices;   /* uint32_t[] */
+    rb_field bvh_triangles; /* rb_gpu_triangle[] */
+    rb_field textures;      /* rb_texture[] */
+} rb_config;
+
+/* ------------------------------------------------------------------------ */
+/* Status codes.  1..10 mirror RenderConfigBuilderError
+ * (crates/engine-config/src/render_config.rs:608-619); the rest replace the
+ * reference's panics / anyhow errors.                                        */
+/* ------------------------------------------------------------------------ */
+enum {
+    RB_OK = 0,
+    RB_ERR_PANE_DISTANCE_OUT_OF_BOUNDS = 1,
+    RB_ERR_PANE_WIDTH_OUT_OF_BOUNDS = 2,
+    RB_ERR_INVALID_CAMERA_DIRECTION = 3,
+    RB_ERR_INVALID_UNIFORMS = 4,
+    RB_ERR_INVALID_SPHERES = 5,
+    RB_ERR_INVALID_UVS = 6,
+    RB_ERR_INVALID_MESHES = 7,
+    RB_ERR_INVALID_LIGHTS = 8,
+    RB_ERR_INVALID_TEXTURES = 9,
+    RB_ERR_CANNOT_DELETE_NONEXISTENT = 10,
+    RB_ERR_UNIFORMS_NOT_INITIALIZED = 11, /* gpu_wrapper.rs:313,321 panic */
+    RB_ERR_NO_MORE_FRAMES = 12,           /* engine-pathtracer/src/lib.rs:170-177 */
+    RB_ERR_INVALID_BVH = 13,              /* malformed tree (cycle, range, depth) */
+    RB_ERR_UNSUPPORTED_DELETE = 14,       /* render_config.rs `todo!()` arms */
+    RB_ERR_NULL_ARGUMENT = 15,
+    RB_ERR_DEVICE = 16,                   /* HIP runtime failure */
+    RB_ERR_NOT_INITIALIZED = 17,          /* render before the first update */
+    RB_ERR_INVALID_OPTIONS = 18
+};
+
+typedef struct rb_engine rb_engine;
+
+/* Options that have no counterpart in the reference (one wgpu device, whole
+ * frame): device choice, row-stripe sharding for multi-GPU, launch shape. */
+typedef struct rb_options {
+    int32_t device;             /* HIP device ordinal; -1 = current */
+    uint32_t shard_rank;        /* this engine renders stripes s with s % shard_count == shard_rank */
+    uint32_t shard_count;       /* 0 or 1 = whole frame */
+    uint32_t stripe_rows;       /* rows per stripe; 0 = default (16) */
+    uint32_t passes_per_launch; /* samples per pixel folded into one kernel launch; 0 = default */
+    uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
+    uint32_t flags;             /* RB_FLAG_* */
+    uint32_t _reserved[5];
+} rb_options;
+
+enum {
+    RB_KERNEL_DEFAULT = 0,
+    RB_KERNEL_PIXEL = 1,  /* one thread per pixel, nested sample/depth loops */
+    RB_KERNEL_QUEUE = 2   /* persistent wavefronts, pixel queue + path regeneration */
+};
+
+enum {
+    RB_FLAG_STATS = 1u  /* count nodes/tris/spheres/lights per segment (slower) */
+};
+
+/* Work counters, summed over every launch since the last rb_reset_stats.
+ * `segments` is the throughput unit (one executed iteration of the bounce
+ * loop, shader.wgsl:534); the rest feed the algorithmic-bytes formula of
+ * SURVEY.md section 8(d) and are only filled when RB_FLAG_STATS is set. */
+typedef struct rb_stats {
+    uint64_t segments;
+    uint64_t paths;
+    uint64_t nodes_popped;
+    uint64_t tris_tested;
+    uint64_t spheres_tested;
+    uint64_t lights_tested;
+    uint64_t mesh_hits;
+    uint64_t launches;
+    double kernel_ms; /* sum of HIP-event durations of the render launches */
+} rb_stats;
+
+/* ------------------------------------------------------------------------ */
+/* Entry points                                                             */
+/* ------------------------------------------------------------------------ */
+
+/* Engine::new(rc) -- crates/engine-pathtracer/src/lib.rs:111-119 ->
+ * GpuWrapper::new, gpu_wrapper.rs:82-105.  Requires Create for uniforms,
+ * spheres, uvs, meshes, lights, textures (buffers.rs:74-97 panics otherwise;
+ * here: NULL + rb_last_error(NULL)).  The engine is not yet "initialized":
+ * the first rb_update must again carry Create (gpu_wrapper.rs:117-121). */
+rb_engine* rb_create(const rb_config* cfg);
+rb_engine* rb_create_ex(const rb_config* cfg, const rb_options* opt);
+
+/* drop(Engine) */
+void rb_destroy(rb_engine* e);
+
+/* GpuWrapper::update + update_uniforms -- gpu_wrapper.rs:116-300,469-576:
+ * Change state machine, validate_init / validate
+ * (render_config.rs:163-268), count patch-up, uploads. */
+int rb_update(rb_engine* e, const rb_config* cfg);
+
+/* GpuWrapper::dispatch_compute + read_pixels -- gpu_wrapper.rs:406-426,432-463:
+ * zero accumulation, run all total_samples passes, return RGBA8 (w*h*4 bytes,
+ * row-major, top row first, x mirrored, A=255) into rgba_out. */
+int rb_render(rb_engine* e, uint8_t* rgba_out);
+
+/* <Engine as Renderer>::render(rc) -- engine-pathtracer/src/lib.rs:58-71:
+ * rb_update + rb_render in one call. */
+int rb_render_config(rb_engine* e, const rb_config* cfg, uint8_t* rgba_out);
+
+/* <Engine as Renderer>::frame_iterator(rc) -- lib.rs:86-96: rb_update, then
+ * current_pass = 0.  One iterator per engine at a time (the reference shares
+ * one GpuWrapper behind a mutex the same way). */
+int rb_iter_begin(rb_engine* e, const rb_config* cfg);
+/* RaytracerFrameIterator::has_next -- lib.rs:153-156 */
+int rb_iter_has_next(rb_engine* e);
+/* RaytracerFrameIterator::next -- lib.rs:169-228: first call zeroes the
+ * accumulation; one pass; read back; current_pass += 1.
+ * Exhausted => RB_ERR_NO_MORE_FRAMES ("No more frames available"). */
+int rb_iter_next(rb_engine* e, uint8_t* rgba_out);
+/* RaytracerFrameIterator::destroy -- lib.rs:231-233 */
+void rb_iter_destroy(rb_engine* e);
+
+/* anyhow error text of the last failing call on `e` (or of rb_create when
+ * e == NULL).  Valid until the next call on the same engine/thread. */
+const char* rb_last_error(const rb_engine* e);
+
+/* GpuWrapper::get_width/get_height -- gpu_wrapper.rs:317-329 */
+int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height);
+
+/* ---- Lower-level control used by bench.py, the parity tests and the
+ * multi-GPU gather.  No reference counterpart: the reference can only run
+ * whole renders synchronously. ---- */
+
+/* Zero the accumulation buffer (gpu_wrapper.rs:407-411). */
+int rb_clear(rb_engine* e);
+/* Launch passes [first_pass, first_pass+n_passes) asynchronously on the
+ * engine's stream (dispatch_compute_progressive, gpu_wrapper.rs:365-400,
+ * without the per-pass host sync). */
+int rb_dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes);
+/* Wait for the engine's stream. */
+int rb_sync(rb_engine* e);
+/* Copy this engine's RGBA8 rows (mirrored, local stripe order) to the host. */
+int rb_read_rgba(rb_engine* e, uint8_t* rgba_out);
+/* Copy the f32 accumulation (vec4 per pixel, shader x order, local stripe
+ * order) to the host: local_rows*width*4 floats. */
+int rb_read_accumulation(rb_engine* e, float* accum_out);
+/* Device pointer + byte size of the local RGBA8 stripe buffer, for an RCCL
+ * gather issued by the caller. */
+int rb_device_rgba(rb_engine* e, void** d_ptr, size_t* bytes);
+/* Number of image rows this engine owns (== height when not sharded) and
+ * the padded row count of the local buffer (equal on every rank). */
+int rb_local_rows(const rb_engine* e, uint32_t* rows, uint32_t* padded_rows);
+/* Global row index of local row `local_row`. */
+int rb_global_row(const rb_engine* e, uint32_t local_row, uint32_t* global_row);
+
+int rb_get_stats(rb_engine* e, rb_stats* out);
+int rb_reset_stats(rb_engine* e);
+/* Duration of the most recent rb_dispatch launch group, HIP events on the
+ * engine's stream (ms).  Synchronises. */
+int rb_last_dispatch_ms(rb_engine* e, float* ms);
+
+/* BVH::new -- crates/engine-bvh/src/bvh.rs:87-150: median split on the longest
+ * axis, leaves of <= 128 triangles, pre-order numbering.  Two-call protocol:
+ * pass nodes_out == NULL to query sizes.  indices_out must hold n_tris u32. */
+int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
+                 rb_bvh_node* nodes_out, size_t nodes_capacity, size_t* n_nodes,
+                 uint32_t* indices_out);
+
+/* Test hook: evaluates the device's f32 /, sqrt, normalize, u32->f32, min/max and
+ * dot on n input pairs (out8n: 8*n floats) so tests can check them against
+ * IEEE-754 results computed on the host. */
+int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
+
+/* Library / device identification for logs. */
+const char* rb_version(void);
+int rb_device_name(int device, char* buf, size_t buf_len);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(rb_camera) == 48, "Camera is 48 B");
+static_assert(sizeof(rb_uniforms) == 144, "Uniforms is 144 B");
+static_assert(sizeof(rb_material) == 80, "Material is 80 B");
+static_assert(sizeof(rb_sphere) == 96, "Sphere is 96 B");
+static_assert(sizeof(rb_point_light) == 96, "PointLight is 96 B");
+static_assert(sizeof(rb_mesh) == 96, "Mesh is 96 B");
+static_assert(sizeof(rb_bvh_node) == 48, "BVHNode is 48 B");
+static_assert(sizeof(rb_gpu_triangle) == 64, "GPUTriangle is 64 B");
+static_assert(sizeof(rb_texture_info) == 16, "TextureInfo is 16 B");
+static_assert(sizeof(rb_progressive) == 16, "ProgressiveRenderHelper is 16 B");
+static_assert(offsetof(rb_uniforms, camera) == 16, "camera @16");
+static_assert(offsetof(rb_uniforms, spheres_count) == 64, "spheres_count @64");
+static_assert(offsetof(rb_uniforms, ground_height) == 84, "ground_height @84");
+static_assert(offsetof(rb_uniforms, sky_color) == 96, "sky_color @96");
+static_assert(offsetof(rb_uniforms, max_depth) == 108, "max_depth @108");
+static_assert(offsetof(rb_uniforms, checkerboard_color_1) == 112, "cb1 @112");
+static_assert(offsetof(rb_uniforms, checkerboard_color_2) == 128, "cb2 @128");
+static_assert(offsetof(rb_camera, pos) == 16, "pos @16");
+static_assert(offsetof(rb_camera, dir) == 32, "dir @32");
+static_assert(offsetof(rb_material, diffuse) == 16, "diffuse @16");
+static_assert(offsetof(rb_material, specular) == 32, "specular @32");
+static_assert(offsetof(rb_material, shininess) == 44, "shininess @44");
+static_assert(offsetof(rb_material, emissive) == 48, "emissive @48");
+static_assert(offsetof(rb_material, texture_index) == 72, "texture_index @72");
+static_assert(offsetof(rb_bvh_node, left) == 32, "left @32");
+static_assert(offsetof(rb_gpu_triangle, mesh_index) == 48, "mesh_index @48");
+#else
+_Static_assert(sizeof(rb_camera) == 48, "Camera is 48 B");
+_Static_assert(sizeof(rb_uniforms) == 144, "Uniforms is 144 B");
+_Static_assert(sizeof(rb_material) == 80, "Material is 80 B");
+_Static_assert(sizeof(rb_sphere) == 96, "Sphere is 96 B");
+_Static_assert(sizeof(rb_point_light) == 96, "PointLight is 96 B");
+_Static_assert(sizeof(rb_mesh) == 96, "Mesh is 96 B");
+_Static_assert(sizeof(rb_bvh_node) == 48, "BVHNode is 48 B");
+_Static_assert(sizeof(rb_gpu_triangle) == 64, "GPUTriangle is 64 B");
+_Static_assert(sizeof(rb_texture_info) == 16, "TextureInfo is 16 B");
+_Static_assert(sizeof(rb_progressive) == 16, "ProgressiveRenderHelper is 16 B");
+#endif
+
+#endif /* RB_ABI_H */

@@ -1,0 +1,79 @@
+"""Loader for librenderbaby_hip.so (the C ABI of include/rb_abi.h).
+
+The product path has no fallback: if the HIP library is missing or fails to
+load, importing the engine raises.  ``torch`` is imported first on purpose: its
+wheel bundles a HIP runtime with the same SONAME (libamdhip64.so.7), and a
+process must not end up with two HIP runtimes if device pointers are to be
+shared with torch.distributed (the RCCL gather).
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librenderbaby_hip.so")
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the render path.")
+    try:
+        import torch  # noqa: F401  (see module docstring)
+    except Exception:  # pragma: no cover - torch is optional for pure C-ABI use
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    P = C.POINTER
+    vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
+    sig = {
+        "rb_create": (vp, [P(abi.Config)]),
+        "rb_create_ex": (vp, [P(abi.Config), P(abi.Options)]),
+        "rb_destroy": (None, [vp]),
+        "rb_update": (i32, [vp, P(abi.Config)]),
+        "rb_render": (i32, [vp, vp]),
+        "rb_render_config": (i32, [vp, P(abi.Config), vp]),
+        "rb_iter_begin": (i32, [vp, P(abi.Config)]),
+        "rb_iter_has_next": (i32, [vp]),
+        "rb_iter_next": (i32, [vp, vp]),
+        "rb_iter_destroy": (None, [vp]),
+        "rb_last_error": (C.c_char_p, [vp]),
+        "rb_get_size": (i32, [vp, P(u32), P(u32)]),
+        "rb_clear": (i32, [vp]),
+        "rb_dispatch": (i32, [vp, u32, u32]),
+        "rb_sync": (i32, [vp]),
+        "rb_read_rgba": (i32, [vp, vp]),
+        "rb_read_accumulation": (i32, [vp, vp]),
+        "rb_device_rgba": (i32, [vp, P(vp), P(sz)]),
+        "rb_local_rows": (i32, [vp, P(u32), P(u32)]),
+        "rb_global_row": (i32, [vp, u32, P(u32)]),
+        "rb_get_stats": (i32, [vp, P(abi.Stats)]),
+        "rb_reset_stats": (i32, [vp]),
+        "rb_last_dispatch_ms": (i32, [vp, P(C.c_float)]),
+        "rb_bvh_build": (i32, [vp, sz, vp, sz, P(sz), vp]),
+        "rb_debug_math": (i32, [vp, vp, vp, u32]),
+        "rb_version": (C.c_char_p, []),
+        "rb_device_name": (i32, [i32, C.c_char_p, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["rb_create", "rb_create_ex", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
+           "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_last_error",
+           "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
+           "rb_device_rgba", "rb_local_rows", "rb_global_row", "rb_get_stats", "rb_reset_stats",
+           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_math", "rb_version", "rb_device_name"]

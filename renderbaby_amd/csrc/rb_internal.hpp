@@ -1,0 +1,89 @@
+// rb_internal.hpp -- declarations shared by the runtime (rb_runtime.cpp), the
+// BVH helper (rb_bvh.cpp) and the kernels (rb_kernels.hip).  Not part of the ABI.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rb_abi.h"
+
+namespace rb {
+
+constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (LDS)
+constexpr uint32_t kDefaultStripeRows = 16;
+
+// ---- rb_bvh.cpp
+void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_node>& nodes,
+               std::vector<uint32_t>& indices);
+bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_stack, std::string& why,
+                  uint32_t* depth_out);
+
+// ---- device-side counters (one block of u64 in device memory)
+enum Counter : uint32_t {
+    C_SEGMENTS = 0, C_PATHS, C_NODES, C_TRIS, C_SPHERES, C_LIGHTS, C_MESH_HITS, C_COUNT
+};
+
+// Triangle in bvh_indices order with the per-triangle invariants of
+// shader.wgsl:249-250,351 hoisted out of the per-ray loop.  edge1/edge2/normal
+// are computed on the device by the same f32 operations the shader performs per
+// test, so every ray sees bit-identical values.
+struct alignas(16) PrepTri {
+    float v0[3];
+    uint32_t tri_id;    // index into bvh_triangles (for hash_to_color and the :336 guard)
+    float e1[3];
+    uint32_t mesh_index;
+    float e2[3];
+    uint32_t valid;     // 0 when a guard of shader.wgsl:331,336 would `continue`
+};
+struct alignas(16) PrepTriShade {
+    float n[3];         // normalize(cross(e1, e2))
+    uint32_t v0_index;
+    uint32_t v1_index;
+    uint32_t v2_index;
+    uint32_t _pad[2];
+};
+
+// Everything a render launch needs.  Passed by value (kernarg segment => scalar loads).
+struct KParams {
+    rb_uniforms u;  // counts already patched (gpu_wrapper.rs:475-495) and clamped to buffer lengths
+    const rb_sphere* spheres;
+    const rb_point_light* lights;
+    const rb_mesh* meshes;
+    const rb_bvh_node* nodes;
+    const uint32_t* indices;
+    const rb_gpu_triangle* tris;
+    const PrepTri* ptris;          // index_len entries, bvh_indices order
+    const PrepTriShade* pshade;    // index_len entries
+    const float* uvs;
+    const uint32_t* tex_data;
+    const rb_texture_info* tex_info;
+    const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
+    float* accum;                  // local_rows_padded * width * 4
+    uint32_t* out_rgba;            // local_rows_padded * width, x mirrored
+    unsigned long long* counters;  // C_COUNT
+    uint32_t* queue;               // work-queue head (RB_KERNEL_QUEUE)
+    uint32_t n_lights;             // arrayLength(&point_lights): >= 1 unless deleted
+    uint32_t n_meshes;
+    uint32_t index_len;            // arrayLength(&bvh_indices)
+    uint32_t n_uvs;
+    uint32_t n_tex;
+    uint32_t first_pass, n_passes, samples_per_pass;
+    uint32_t shard_rank, shard_count, stripe_rows, local_rows;  // local_rows: rows owned (unpadded)
+};
+
+struct LaunchInfo {
+    uint32_t grid, block;
+    size_t lds_bytes;
+};
+
+// ---- rb_kernels.hip
+// All return hipError_t as int (0 = success); launches are asynchronous on `stream`.
+int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream, LaunchInfo* info);
+int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
+                     uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
+int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);
+int device_cu_count(int device);
+
+}  // namespace rb

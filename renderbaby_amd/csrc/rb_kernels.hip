@@ -1,0 +1,774 @@
+// rb_kernels.hip -- gfx950 (CDNA4, wave64) kernels for RenderBaby's path-tracing
+// hot path: the per-pixel / per-sample loop of
+// crates/engine-pathtracer/src/shader.wgsl (main :673-723, trace_ray :522-662,
+// intersect_bvh :282-392, intersect_* :193-280,402-414,664-671, PCG :417-446,
+// scatter :459-490, sample_texture :153-191, color_map :137-151).
+//
+// Numerics contract (bit-exact against oracle/rb_oracle.c; DESIGN.md "Numerics"):
+//   every f32 operation is a single IEEE binary32 op, round-to-nearest-even, no FMA
+//   contraction (this TU is built with -ffp-contract=off and the pragma below),
+//   correctly-rounded / and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt),
+//   subnormals kept (hipcc default float mode), dot = (x*x' + y*y') + z*z'.
+//
+// No MFMA: the work is branchy traversal and 3-wide dot products.  What matters
+// here is lane utilisation (path regeneration keeps all 64 lanes on the
+// intersection code), scalar/LDS residency of the scene, and 16-byte loads.
+#include <hip/hip_runtime.h>
+
+#include "rb_internal.hpp"
+
+#pragma clang fp contract(off)
+
+#define DEV __device__ __forceinline__
+
+namespace rb {
+namespace {
+
+// ------------------------------------------------------------------ vec3 --
+struct f3 {
+    float x, y, z;
+};
+DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+DEV f3 divs(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV f3 normalize(f3 a) { return divs(a, sqrtf(dot(a, a))); }
+
+// WGSL u32(f32) / i32(f32): truncate + saturate, NaN -> 0
+DEV uint32_t f2u(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+DEV int32_t f2i(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)f;
+}
+
+// ------------------------------------------------------------------- RNG --
+// shader.wgsl:417-421
+DEV uint32_t pcg(uint32_t seed) {
+    uint32_t state = seed * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+// shader.wgsl:423-426
+DEV float rnd(uint32_t& seed) {
+    seed = pcg(seed);
+    return (float)seed / 4294967296.0f;
+}
+// shader.wgsl:429-446
+DEV f3 random_unit_vector(uint32_t& seed) {
+    f3 p;
+    for (;;) {
+        float px = rnd(seed) * 2.0f - 1.0f;
+        float py = rnd(seed) * 2.0f - 1.0f;
+        float pz = rnd(seed) * 2.0f - 1.0f;
+        p = mk(px, py, pz);
+        if (dot(p, p) < 1.0f) break;
+    }
+    return normalize(p);
+}
+
+// --------------------------------------------------------- colour output --
+DEV float linear_to_gamma(float c) { return (c > 0.0f) ? sqrtf(c) : 0.0f; }  // :137-142
+DEV uint32_t color_map(f3 c) {                                                // :144-151
+    uint32_t r = f2u(linear_to_gamma(c.x) * 255.999f);
+    uint32_t g = f2u(linear_to_gamma(c.y) * 255.999f);
+    uint32_t b = f2u(linear_to_gamma(c.z) * 255.999f);
+    return (255u << 24) | (b << 16) | (g << 8) | r;
+}
+DEV f3 hash_to_color(uint32_t n) {  // :394-400
+    uint32_t h = n * 2654435761u;
+    return mk((float)(h % 41u) / 40.0f, (float)(h % 29u) / 28.0f, (float)(h % 19u) / 18.0f);
+}
+
+// -------------------------------------------------------------- textures --
+// shader.wgsl:153-191.  pow(c, 2.2) over the 256 possible channel values is a
+// host-computed table (same libm as the oracle), so textured hits stay bit-exact.
+DEV f3 sample_texture(const KParams& p, int32_t index, float uvx, float uvy) {
+    if (index < 0) {
+        if (p.u.checkerboard_enabled > 0u) {
+            int32_t u2 = f2i(floorf(uvx * 10.0f));
+            int32_t v2 = f2i(floorf(uvy * 10.0f));
+            int32_t sum = (int32_t)((uint32_t)u2 + (uint32_t)v2);
+            return (sum % 2 == 0) ? ld3(p.u.checkerboard_color_1) : ld3(p.u.checkerboard_color_2);
+        }
+        return mk(1.0f, 1.0f, 1.0f);
+    }
+    if ((uint32_t)index >= p.n_tex) return mk(0.0f, 0.0f, 0.0f);
+    const rb_texture_info info = p.tex_info[index];
+    float u = uvx - floorf(uvx);
+    float v = uvy - floorf(uvy);
+    uint32_t x = min(f2u(u * (float)info.width), info.width - 1u);
+    uint32_t y = min(f2u((1.0f - v) * (float)info.height), info.height - 1u);
+    uint32_t pixel = p.tex_data[info.offset + y * info.width + x];
+    return mk(p.srgb_lut[pixel & 255u], p.srgb_lut[(pixel >> 8) & 255u], p.srgb_lut[(pixel >> 16) & 255u]);
+}
+
+// ---------------------------------------------------------- intersection --
+// shader.wgsl:193-215 / :217-239
+DEV float isect_sphere(f3 o, f3 d, float a, f3 center, float radius) {
+    f3 oc = o - center;
+    float half_b = dot(oc, d);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return -1.0f;
+    float sqrtd = sqrtf(disc);
+    float root = (-half_b - sqrtd) / a;
+    if (root <= 0.001f) {
+        root = (-half_b + sqrtd) / a;
+        if (root <= 0.001f) return -1.0f;
+    }
+    return root;
+}
+
+// shader.wgsl:248-280 with edge1/edge2 supplied (v1 - v0, v2 - v0)
+DEV float isect_triangle(f3 o, f3 d, f3 v0, f3 edge1, f3 edge2, float& uo, float& vo) {
+    f3 h = cross(d, edge2);
+    float a = dot(edge1, h);
+    if (fabsf(a) < 1e-6f) return -1.0f;
+    float f = 1.0f / a;
+    f3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    f3 q = cross(s, edge1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    float t = f * dot(edge2, q);
+    if (t > 0.0f) {
+        uo = u;
+        vo = v;
+        return t;
+    }
+    return -1.0f;
+}
+
+// shader.wgsl:664-671 with inv_dir = 1/dir hoisted per ray (pure function of dir)
+DEV bool isect_aabb(f3 o, f3 inv, f3 bmin, f3 bmax) {
+    f3 t0 = (bmin - o) * inv;
+    f3 t1 = (bmax - o) * inv;
+    float tmin = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+    float tmax = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+    return tmax >= fmaxf(tmin, 0.0f);
+}
+
+// shader.wgsl:402-414
+DEV float isect_ground(f3 o, f3 d, float ground_height) {
+    if (fabsf(d.y) < 1e-6f) return -1.0f;
+    float t = (ground_height - o.y) / d.y;
+    return (t > 0.0f) ? t : -1.0f;
+}
+
+// ------------------------------------------------------------ statistics --
+template <bool STATS>
+struct Tally {
+    uint32_t segments = 0, paths = 0;
+    unsigned long long nodes = 0, tris = 0, spheres = 0, lights = 0, mesh_hits = 0;
+};
+template <>
+struct Tally<false> {
+    uint32_t segments = 0, paths = 0;
+};
+
+DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <bool STATS>
+DEV void flush_tally(const Tally<STATS>& t, unsigned long long* counters) {
+    unsigned long long seg = wave_sum((unsigned long long)t.segments);
+    unsigned long long pth = wave_sum((unsigned long long)t.paths);
+    const bool lead = (__lane_id() == 0);
+    if (lead) {
+        atomicAdd(&counters[C_SEGMENTS], seg);
+        atomicAdd(&counters[C_PATHS], pth);
+    }
+    if constexpr (STATS) {
+        unsigned long long a = wave_sum(t.nodes), b = wave_sum(t.tris), c = wave_sum(t.spheres),
+                           d = wave_sum(t.lights), e = wave_sum(t.mesh_hits);
+        if (lead) {
+            atomicAdd(&counters[C_NODES], a);
+            atomicAdd(&counters[C_TRIS], b);
+            atomicAdd(&counters[C_SPHERES], c);
+            atomicAdd(&counters[C_LIGHTS], d);
+            atomicAdd(&counters[C_MESH_HITS], e);
+        }
+    }
+}
+
+// -------------------------------------------------------- BVH traversal --
+struct TriHit {
+    float t, u, v;
+    uint32_t slot;  // position in bvh_indices (prepared-triangle index)
+    bool hit;
+};
+
+// shader.wgsl:282-392.  Same visit order (left pushed first, right popped first),
+// same strict `t > 0.001 && t < hit.t` acceptance, so the winner is the same
+// triangle.  Shading data of shader.wgsl:350-372 depends only on the final
+// winner and is produced afterwards (tri_shade).  `stack` is this lane's column
+// of an LDS array [kStackDepth][blockDim]; the host has verified that the tree
+// fits (rb_bvh.cpp).
+template <bool STATS>
+DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    TriHit h;
+    h.hit = false;
+    h.t = 1e20f;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.slot = 0u;
+    const uint32_t node_count = p.u.bvh_node_count;
+    if (node_count == 0u) return h;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    stack[0] = 0u;
+    sp = 1;
+    while (sp > 0) {
+        sp--;
+        const uint32_t node_idx = stack[sp * stride];
+        if (node_idx >= node_count) continue;
+        const float4* np = reinterpret_cast<const float4*>(p.nodes + node_idx);
+        const float4 n0 = np[0], n1 = np[1];
+        const uint4 n2 = reinterpret_cast<const uint4*>(np)[2];
+        if constexpr (STATS) tl.nodes++;
+        if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
+        const uint32_t left = n2.x, right = n2.y, first = n2.z, count = n2.w;
+        if (count > 0u) {
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t slot = first + i;
+                if (slot >= p.index_len) continue;
+                const float4* tp = reinterpret_cast<const float4*>(p.ptris + slot);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+                if constexpr (STATS) tl.tris++;
+                float u, v;
+                const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+                if (t > 0.001f && t < h.t) {
+                    h.hit = true;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.slot = slot;
+                    if constexpr (STATS) tl.mesh_hits++;
+                }
+            }
+        } else {
+            if (left < node_count) {
+                stack[sp * stride] = left;
+                sp++;
+            }
+            if (right < node_count) {
+                stack[sp * stride] = right;
+                sp++;
+            }
+        }
+    }
+    return h;
+}
+
+DEV float uv_at(const KParams& p, uint32_t i) { return (i < p.n_uvs) ? p.uvs[i] : 0.0f; }
+
+// shader.wgsl:353-361
+DEV void tri_uv(const KParams& p, const TriHit& h, float& uvx, float& uvy) {
+    const PrepTriShade s = p.pshade[h.slot];
+    const float w = 1.0f - h.u - h.v;
+    const float uv0x = uv_at(p, s.v0_index * 2u), uv0y = uv_at(p, s.v0_index * 2u + 1u);
+    const float uv1x = uv_at(p, s.v1_index * 2u), uv1y = uv_at(p, s.v1_index * 2u + 1u);
+    const float uv2x = uv_at(p, s.v2_index * 2u), uv2y = uv_at(p, s.v2_index * 2u + 1u);
+    uvx = (w * uv0x + h.u * uv1x) + h.v * uv2x;
+    uvy = (w * uv0y + h.u * uv1y) + h.v * uv2y;
+}
+
+// ------------------------------------------------------------- materials --
+struct Mat {
+    f3 diffuse, specular, emissive;
+    float shininess;
+    int32_t tex;
+};
+DEV Mat load_mat(const rb_material* m) {
+    const float4* q = reinterpret_cast<const float4*>(m);
+    const float4 d = q[1], s = q[2], e = q[3];
+    Mat r;
+    r.diffuse = mk(d.x, d.y, d.z);
+    r.specular = mk(s.x, s.y, s.z);
+    r.shininess = s.w;
+    r.emissive = mk(e.x, e.y, e.z);
+    r.tex = m->texture_index;
+    return r;
+}
+
+enum Kind : uint32_t { K_NONE = 0, K_GROUND = 1, K_TRI = 2, K_SPHERE = 3, K_LIGHT = 4 };
+
+struct Path {
+    f3 o, d;
+    f3 color, att;
+    uint32_t seed;
+    uint32_t depth;
+};
+
+DEV f3 reflect_vector(f3 v, f3 n) { return v - (2.0f * dot(v, n)) * n; }  // :459-461
+DEV bool near_zero(f3 v) {                                                // :463-466
+    const float s = 1e-8f;
+    return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
+}
+
+// One iteration of the bounce loop, shader.wgsl:534-660.  Returns true when the
+// path continues.  The closest-hit search keeps the reference's category order
+// (ground, BVH, spheres, lights) and strict comparisons, so ties resolve the
+// same way; per-hit data that only the final winner needs (position, normal,
+// material, uv) is produced once, after the search.
+template <bool STATS>
+DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    const f3 o = pt.o, d = pt.d;
+    tl.segments++;
+
+    float closest_t = 1e20f;
+    uint32_t kind = K_NONE;
+    // state of closest_hit.uv / use_texture after the ground + BVH stage
+    float uvx = 0.0f, uvy = 0.0f;
+    bool use_tex = false;
+
+    // Ground :552-565
+    if (p.u.ground_enabled > 0u) {
+        const float t = isect_ground(o, d, p.u.ground_height);
+        if (t > 0.001f && t < closest_t) {
+            closest_t = t;
+            kind = K_GROUND;
+            const f3 gp = o + t * d;
+            uvx = gp.x;
+            uvy = gp.z;
+            use_tex = true;
+        }
+    }
+
+    // BVH triangles :568-571
+    const TriHit th = intersect_bvh<STATS>(p, o, d, stack, stride, tl);
+    const bool tri_won_a = th.hit && th.t < closest_t;  // closest_hit = bvh_hit
+    if (tri_won_a) {
+        closest_t = th.t;
+        kind = K_TRI;
+    }
+
+    // Spheres :574-586
+    const float a = dot(d, d);
+    uint32_t sphere_idx = 0xFFFFFFFFu;
+    const uint32_t ns = p.u.spheres_count;
+    for (uint32_t k = 0; k < ns; k++) {
+        const float4 cr = *reinterpret_cast<const float4*>(p.spheres + k);
+        if constexpr (STATS) tl.spheres++;
+        const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+        if (t > 0.001f && t < closest_t) {
+            closest_t = t;
+            sphere_idx = k;
+        }
+    }
+    if (sphere_idx != 0xFFFFFFFFu) kind = K_SPHERE;
+
+    // Point lights :590-601
+    uint32_t light_idx = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < p.n_lights; k++) {
+        const float4 cr = *reinterpret_cast<const float4*>(p.lights + k);
+        if constexpr (STATS) tl.lights++;
+        const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+        if (t > 0.001f && t < closest_t) {
+            closest_t = t;
+            light_idx = k;
+        }
+    }
+    if (light_idx != 0xFFFFFFFFu) kind = K_LIGHT;
+
+    // Sky :604-608
+    if (kind == K_NONE) {
+        pt.color = pt.color + pt.att * ld3(p.u.sky_color);
+        return false;
+    }
+
+    // ---- resolve the winner's HitRecord fields (:555-563, :348-372, :579-584, :595-599)
+    const f3 pos = o + closest_t * d;
+    f3 normal = mk(0.0f, 1.0f, 0.0f);
+    Mat m;
+    m.diffuse = mk(0, 0, 0);
+    m.specular = mk(0, 0, 0);
+    m.emissive = mk(0, 0, 0);
+    m.shininess = 0.0f;
+    m.tex = -1;
+    if (tri_won_a) {
+        // the BVH hit replaced closest_hit, including uv and use_texture, even if a
+        // sphere or light wins later (those never reset uv; lights never reset use_texture)
+        const PrepTri* pr = p.ptris + th.slot;
+        if (p.u.color_hash_enabled != 0u) {
+            use_tex = false;
+            if (kind == K_TRI) m.diffuse = hash_to_color(pr->tri_id + 1u);
+        } else {
+            const rb_material* mm = &p.meshes[pr->mesh_index].material;
+            if (kind == K_TRI) {
+                m = load_mat(mm);
+                use_tex = m.tex >= 0;
+            } else {
+                use_tex = mm->texture_index >= 0;
+            }
+        }
+    }
+    if (kind == K_GROUND) {
+        m.diffuse = mk(0.5f, 0.5f, 0.5f);
+    } else if (kind == K_TRI) {
+        const PrepTriShade s = p.pshade[th.slot];
+        normal = mk(s.n[0], s.n[1], s.n[2]);
+    } else {
+        if (sphere_idx != 0xFFFFFFFFu) {
+            const rb_sphere* s = p.spheres + sphere_idx;
+            if (kind == K_SPHERE) {
+                m = load_mat(&s->material);
+                use_tex = m.tex >= 0;
+                normal = normalize(pos - ld3(s->center));
+            } else {
+                use_tex = s->material.texture_index >= 0;
+            }
+        }
+        if (kind == K_LIGHT) {
+            const rb_point_light* l = p.lights + light_idx;
+            m = load_mat(&l->material);
+            normal = normalize(pos - ld3(l->center));
+        }
+    }
+
+    const float specular_strength = (m.specular.x + m.specular.y + m.specular.z) / 3.0f;
+    const float diffuse_strength = (m.diffuse.x + m.diffuse.y + m.diffuse.z) / 3.0f;
+    const bool is_metal = specular_strength > 0.01f && diffuse_strength < 0.01f;
+
+    pt.color = pt.color + pt.att * m.emissive;  // :626
+
+    f3 scattered, albedo;
+    if (is_metal) {
+        const float fuzz = fminf(fmaxf(1.0f - (m.shininess / 1000.0f), 0.0f), 1.0f);
+        const f3 reflected = reflect_vector(normalize(d), normal);
+        scattered = reflected + fuzz * random_unit_vector(pt.seed);
+        if (dot(scattered, normal) <= 0.0f) return false;
+        albedo = m.specular;
+    } else {
+        const f3 sd = normal + random_unit_vector(pt.seed);
+        scattered = near_zero(sd) ? normal : normalize(sd);
+        albedo = m.diffuse;
+        if (use_tex) {
+            if (tri_won_a) tri_uv(p, th, uvx, uvy);
+            albedo = albedo * sample_texture(p, m.tex, uvx, uvy);
+        }
+    }
+    pt.att = pt.att * albedo;
+    pt.o = pos + 0.001f * normal;
+    pt.d = normalize(scattered);
+    pt.depth++;
+    return pt.depth < p.u.max_depth;
+}
+
+// ----------------------------------------------------------------- camera --
+struct Cam {
+    f3 pos, right, up, fwd;
+    float fov, aspect, wm1, hm1;
+};
+// shader.wgsl:690,702-708 (per-launch invariants of the sample loop)
+DEV Cam make_cam(const KParams& p) {
+    Cam c;
+    c.aspect = (float)p.u.width / (float)p.u.height;
+    c.pos = ld3(p.u.camera.pos);
+    c.fwd = normalize(ld3(p.u.camera.dir));
+    c.right = normalize(cross(mk(0.0f, 1.0f, 0.0f), c.fwd));
+    c.up = cross(c.fwd, c.right);
+    c.fov = p.u.camera.pane_width / (2.0f * p.u.camera.pane_distance * c.aspect);
+    c.wm1 = (float)(p.u.width - 1u);
+    c.hm1 = (float)(p.u.height - 1u);
+    return c;
+}
+// shader.wgsl:693-709
+DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
+                    uint32_t sample_offset, Path& pt) {
+    uint32_t seed = pcg(pixel_index + pcg(sample_offset));
+    const float off_x = rnd(seed) - 0.5f;
+    const float off_y = rnd(seed) - 0.5f;
+    const float u = ((((float)x + off_x) / c.wm1) * 2.0f - 1.0f) * c.aspect;
+    const float v = 1.0f - (((float)y + off_y) / c.hm1) * 2.0f;
+    pt.o = c.pos;
+    pt.d = normalize(((c.fov * u) * c.right + (c.fov * v) * c.up) + c.fwd);
+    pt.seed = seed;
+    pt.color = mk(0, 0, 0);
+    pt.att = mk(1, 1, 1);
+    pt.depth = 0;
+}
+
+// global image row of local row `ly` (interleaved stripes)
+DEV uint32_t global_row(const KParams& p, uint32_t ly) {
+    if (p.shard_count <= 1u) return ly;
+    const uint32_t s = ly / p.stripe_rows, r = ly % p.stripe_rows;
+    return (s * p.shard_count + p.shard_rank) * p.stripe_rows + r;
+}
+
+// shader.wgsl:716-722 + the x mirror of gpu_wrapper.rs:446-458
+DEV void store_pixel(const KParams& p, uint32_t x, uint32_t ly, f3 acc, uint32_t total_samples) {
+    const size_t li = (size_t)ly * p.u.width + x;
+    const float ts = (float)total_samples;
+    reinterpret_cast<float4*>(p.accum)[li] = make_float4(acc.x, acc.y, acc.z, ts);
+    const f3 fin = divs(acc, ts);
+    const f3 mapped = mk(fin.x / (fin.x + 1.0f), fin.y / (fin.y + 1.0f), fin.z / (fin.z + 1.0f));
+    p.out_rgba[(size_t)ly * p.u.width + (p.u.width - 1u - x)] = color_map(mapped);
+}
+
+// ======================================================= kernel: PIXEL ====
+// One thread per pixel, 8x8 pixels per wavefront, nested sample / bounce loops:
+// the shape of the reference's dispatch (one invocation = one pixel,
+// gpu_wrapper.rs:380-384) with all passes of a launch folded into the kernel.
+constexpr uint32_t kPixelBlock = 256;
+
+template <bool STATS>
+__global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
+    __shared__ uint32_t s_stack[kStackDepth * kPixelBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tiles_x = (p.u.width + 15u) / 16u;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t x = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ly = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Tally<STATS> tl;
+    bool active = (x < p.u.width) && (ly < p.local_rows);
+    uint32_t y = 0;
+    if (active) {
+        y = global_row(p, ly);
+        active = y < p.u.height;
+    }
+    if (active) {
+        const Cam cam = make_cam(p);
+        const uint32_t pixel_index = y * p.u.width + x;
+        const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * p.u.width + x];
+        f3 acc = mk(a4.x, a4.y, a4.z);
+        uint32_t total = f2u(a4.w);
+        for (uint32_t pass = p.first_pass; pass < p.first_pass + p.n_passes; pass++) {
+            for (uint32_t s = 0; s < p.samples_per_pass; s++) {
+                Path pt;
+                start_path(p, cam, x, y, pixel_index, pass * p.samples_per_pass + s, pt);
+                if (p.u.max_depth > 0u) {
+                    while (segment<STATS>(p, pt, &s_stack[tid], kPixelBlock, tl)) {
+                    }
+                }
+                tl.paths++;
+                acc = acc + pt.color;
+                total = total + 1u;
+            }
+        }
+        store_pixel(p, x, ly, acc, total);
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
+// ======================================================= kernel: QUEUE ====
+// Persistent wavefronts.  Each lane owns one pixel at a time and walks its
+// samples in order (so the f32 accumulation order is the reference's); a lane
+// whose path ends starts its next sample immediately (path regeneration), and a
+// lane whose pixel is finished takes the next pixel from a global queue: the
+// wave ballots the idle lanes, lane 0 reserves popcount(idle) pixels with one
+// atomic, and each idle lane picks its slot by prefix count.  All live lanes
+// therefore execute the intersection code together on every iteration.
+constexpr uint32_t kQueueBlock = 256;
+
+template <bool STATS>
+__global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
+    __shared__ uint32_t s_stack[kStackDepth * kQueueBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t total_items = tiles_x * tiles_y * 64u;  // host guarantees < 2^32
+    const uint32_t samples_total = p.n_passes * p.samples_per_pass;
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    const Cam cam = make_cam(p);
+    Tally<STATS> tl;
+
+    bool have_pixel = false;   // lane owns a pixel
+    bool exhausted = false;    // queue is empty for this wave
+    uint32_t x = 0, ly = 0, y = 0, pixel_index = 0, sample = 0, total = 0;
+    f3 acc = mk(0, 0, 0);
+    Path pt;
+    pt.depth = 0;
+    bool in_path = false;
+
+    for (;;) {
+        // ---- refill idle lanes from the queue
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!have_pixel);
+            if (idle != 0ull) {
+                const uint32_t n = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(p.queue, n);
+                base = __shfl(base, __ffsll((long long)idle) - 1, 64);
+                if (!have_pixel) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t item = base + rank;
+                    if (item < total_items) {
+                        const uint32_t tile = item >> 6, in = item & 63u;
+                        x = (tile % tiles_x) * 8u + (in & 7u);
+                        ly = (tile / tiles_x) * 8u + (in >> 3);
+                        bool ok = (x < width) && (ly < p.local_rows);
+                        if (ok) {
+                            y = global_row(p, ly);
+                            ok = y < p.u.height;
+                        }
+                        if (ok) {
+                            pixel_index = y * width + x;
+                            const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * width + x];
+                            acc = mk(a4.x, a4.y, a4.z);
+                            total = f2u(a4.w);
+                            sample = 0;
+                            have_pixel = true;
+                            in_path = false;
+                        }
+                    }
+                }
+                if (base + n >= total_items) exhausted = true;
+            }
+        }
+        if (__ballot(have_pixel) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (have_pixel) {
+            if (!in_path) {
+                start_path(p, cam, x, y, pixel_index, sample_base + sample, pt);
+                in_path = p.u.max_depth > 0u;
+            }
+            if (in_path) in_path = segment<STATS>(p, pt, &s_stack[tid], kQueueBlock, tl);
+            if (!in_path) {
+                tl.paths++;
+                acc = acc + pt.color;
+                total = total + 1u;
+                sample++;
+                if (sample == samples_total) {
+                    store_pixel(p, x, ly, acc, total);
+                    have_pixel = false;
+                }
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
+// ============================================================ prep kernel ==
+// Gathers triangles into bvh_indices order and hoists the per-triangle
+// invariants (edge1, edge2, geometric normal) of shader.wgsl:249-250,351.
+__global__ void k_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
+                            uint32_t index_len, PrepTri* out, PrepTriShade* shade) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= index_len) return;
+    PrepTri t;
+    PrepTriShade s;
+    const uint32_t id = indices[slot];
+    if (id >= tri_count) {  // shader.wgsl:336 `continue`
+        t = PrepTri{};
+        s = PrepTriShade{};
+        t.valid = 0u;
+    } else {
+        const rb_gpu_triangle g = tris[id];
+        const f3 v0 = ld3(g.v0), v1 = ld3(g.v1), v2 = ld3(g.v2);
+        const f3 e1 = v1 - v0, e2 = v2 - v0;
+        const f3 n = normalize(cross(e1, e2));
+        t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
+        t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
+        t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+        t.tri_id = id;
+        t.mesh_index = g.mesh_index;
+        t.valid = 1u;
+        s.n[0] = n.x; s.n[1] = n.y; s.n[2] = n.z;
+        s.v0_index = g.v0_index;
+        s.v1_index = g.v1_index;
+        s.v2_index = g.v2_index;
+        s._pad[0] = s._pad[1] = 0u;
+    }
+    out[slot] = t;
+    shade[slot] = s;
+}
+
+// Exposes the device's /, sqrt, normalize and u32->f32 to the parity tests.
+__global__ void k_debug_math(const float* a, const float* b, float* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    out[i] = x / y;
+    out[n + i] = sqrtf(fabsf(x));
+    const f3 v = normalize(mk(x, y, x * y));
+    out[2 * n + i] = v.x;
+    out[3 * n + i] = v.y;
+    out[4 * n + i] = v.z;
+    out[5 * n + i] = (float)__float_as_uint(x) / 4294967296.0f;
+    out[6 * n + i] = fminf(fmaxf(x, y), x * 0.0f);
+    out[7 * n + i] = dot(mk(x, y, x), mk(y, y, x));
+}
+
+}  // namespace
+
+// ================================================================ launchers ==
+int device_cu_count(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    LaunchInfo li{};
+    if (kernel == RB_KERNEL_PIXEL) {
+        const uint32_t tiles_x = (p.u.width + 15u) / 16u, tiles_y = (p.local_rows + 15u) / 16u;
+        li.grid = tiles_x * tiles_y;
+        li.block = kPixelBlock;
+        li.lds_bytes = sizeof(uint32_t) * kStackDepth * kPixelBlock;
+        if (li.grid == 0) return 0;
+        if (stats)
+            hipLaunchKernelGGL(k_pixel<true>, dim3(li.grid), dim3(li.block), 0, stream, p);
+        else
+            hipLaunchKernelGGL(k_pixel<false>, dim3(li.grid), dim3(li.block), 0, stream, p);
+    } else {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint32_t cus = (uint32_t)device_cu_count(dev);
+        const uint64_t items = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u) * 64u;
+        uint32_t blocks = cus * 4u;  // 16 waves per CU
+        const uint64_t needed = (items + kQueueBlock - 1) / kQueueBlock;
+        if (needed < blocks) blocks = (uint32_t)needed;
+        li.grid = blocks;
+        li.block = kQueueBlock;
+        li.lds_bytes = sizeof(uint32_t) * kStackDepth * kQueueBlock;
+        if (li.grid == 0) return 0;
+        hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return (int)e;
+        if (stats)
+            hipLaunchKernelGGL(k_queue<true>, dim3(li.grid), dim3(li.block), 0, stream, p);
+        else
+            hipLaunchKernelGGL(k_queue<false>, dim3(li.grid), dim3(li.block), 0, stream, p);
+    }
+    if (info) *info = li;
+    return (int)hipGetLastError();
+}
+
+int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
+                     uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream_) {
+    if (index_len == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint32_t block = 256, grid = (index_len + block - 1) / block;
+    hipLaunchKernelGGL(k_prep_tris, dim3(grid), dim3(block), 0, stream, tris, tri_count, indices, index_len, out,
+                       shade);
+    return (int)hipGetLastError();
+}
+
+int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream_) {
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, out, n);
+    return (int)hipGetLastError();
+}
+
+}  // namespace rb

@@ -1,0 +1,805 @@
+// rb_runtime.cpp -- the C-ABI runtime of librenderbaby_hip.so (include/rb_abi.h).
+//
+// Replaces, for the HIP backend, crates/engine-wgpu-wrapper (GpuWrapper,
+// GpuBuffers, ProgressiveRenderHelper) and the host half of
+// crates/engine-pathtracer/src/lib.rs: device buffers mirroring the 14 wgpu
+// buffers (buffers.rs:32-61), the Change<T> state machine
+// (gpu_wrapper.rs:116-300), count patch-up and uploads (:469-576), the pass loop
+// (:365-426) and read-back (:432-463; the x mirror is done by the kernel's
+// store).  Every entry point selects its device first (HIP's current device is
+// per-thread and the reference drives the iterator from a worker thread,
+// frame_buffer.rs:141-148) and reports failures as status + message instead of
+// panicking.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rb_internal.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* ptr = nullptr;
+    size_t count = 0;     // elements allocated
+    ~DevBuf() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    hipError_t resize(size_t n) {
+        if (n == count && ptr) return hipSuccess;
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct rb_engine {
+    std::mutex mu;
+    std::string error;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    rb_options opt{};
+
+    bool initialized = false;        // GpuWrapper::initialized (gpu_wrapper.rs:69,117)
+    bool have_uniforms = false;      // last update carried Create/Update uniforms (:303-329)
+    rb_uniforms uniforms{};          // as handed over (before count patch-up)
+    rb_progressive prh{};            // gpu_wrapper.rs:19-53
+    bool iter_initialized = false;   // RaytracerFrameIterator::initialized (lib.rs:131)
+
+    // element counts = what arrayLength() / the patched uniforms see
+    uint32_t n_spheres = 0, n_lights = 0, n_meshes = 0, n_nodes = 0, n_indices = 0, n_tris = 0, n_uvs = 0,
+             n_tex = 0;
+    // Change of the last update for the three patched counts (gpu_wrapper.rs:475-495)
+    uint32_t last_change_spheres = RB_KEEP, last_change_nodes = RB_KEEP, last_change_tris = RB_KEEP;
+    bool prep_dirty = true;
+
+    DevBuf<rb_sphere> spheres;
+    DevBuf<rb_point_light> lights;
+    DevBuf<rb_mesh> meshes;
+    DevBuf<rb_bvh_node> nodes;
+    DevBuf<uint32_t> indices;
+    DevBuf<rb_gpu_triangle> tris;
+    DevBuf<rb::PrepTri> ptris;
+    DevBuf<rb::PrepTriShade> pshade;
+    DevBuf<float> uvs;
+    DevBuf<uint32_t> tex_data;
+    DevBuf<rb_texture_info> tex_info;
+    DevBuf<float> srgb_lut;
+    DevBuf<float> accum;
+    DevBuf<uint32_t> out_rgba;
+    DevBuf<unsigned long long> counters;
+    DevBuf<uint32_t> queue;
+
+    std::vector<rb_bvh_node> host_nodes;  // kept for validation when nodes/indices change separately
+    uint32_t width = 0, height = 0, local_rows = 0, padded_rows = 0;
+
+    rb_stats stats{};
+    float last_dispatch_ms = 0.0f;
+    uint32_t last_launches = 0;
+    bool timing_pending = false;
+    uint32_t max_mesh_index = 0;  // over the uploaded triangles
+};
+
+namespace {
+
+int fail(rb_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                          \
+    do {                                                                                          \
+        hipError_t _st = (call);                                                                  \
+        if (_st != hipSuccess)                                                                    \
+            return fail((e), RB_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_st));      \
+    } while (0)
+
+const char* kFieldNames[9] = {"uniforms", "spheres", "uvs", "meshes", "lights",
+                              "bvh_nodes", "bvh_indices", "bvh_triangles", "textures"};
+
+const rb_field* field_at(const rb_config* c, int i) {
+    const rb_field* f[9] = {&c->uniforms, &c->spheres, &c->uvs, &c->meshes, &c->lights,
+                            &c->bvh_nodes, &c->bvh_indices, &c->bvh_triangles, &c->textures};
+    return f[i];
+}
+
+int check_fields(rb_engine* e, const rb_config* cfg) {
+    if (!cfg) return fail(e, RB_ERR_NULL_ARGUMENT, "config is NULL");
+    for (int i = 0; i < 9; ++i) {
+        const rb_field* f = field_at(cfg, i);
+        if (f->change > RB_DELETE) return fail(e, RB_ERR_NULL_ARGUMENT, "%s: bad change tag %u", kFieldNames[i], f->change);
+        if ((f->change == RB_CREATE || f->change == RB_UPDATE) && f->count > 0 && !f->ptr)
+            return fail(e, RB_ERR_NULL_ARGUMENT, "%s: count %zu with NULL pointer", kFieldNames[i], f->count);
+    }
+    if ((cfg->uniforms.change == RB_CREATE || cfg->uniforms.change == RB_UPDATE) && cfg->uniforms.count != 1)
+        return fail(e, RB_ERR_INVALID_UNIFORMS, "uniforms: expected exactly one rb_uniforms, got %zu", cfg->uniforms.count);
+    return RB_OK;
+}
+
+// RenderConfig::validate_init -- render_config.rs:163-185
+int validate_init(rb_engine* e, const rb_config* c) {
+    if (c->uniforms.change != RB_CREATE) return fail(e, RB_ERR_INVALID_UNIFORMS, "Invalid Uniforms");
+    if (c->spheres.change != RB_CREATE) return fail(e, RB_ERR_INVALID_SPHERES, "Invalid Spheres");
+    if (c->uvs.change != RB_CREATE) return fail(e, RB_ERR_INVALID_UVS, "Invalid UVs");
+    if (c->meshes.change != RB_CREATE) return fail(e, RB_ERR_INVALID_MESHES, "Invalid Meshes");
+    if (c->lights.change != RB_CREATE) return fail(e, RB_ERR_INVALID_LIGHTS, "Invalid Lights");
+    if (c->textures.change != RB_CREATE) return fail(e, RB_ERR_INVALID_TEXTURES, "Invalid Textures");
+    return RB_OK;
+}
+
+bool has_data(const rb_field& f) { return f.change == RB_CREATE || f.change == RB_UPDATE; }
+
+// RenderConfig::validate -- render_config.rs:187-268
+int validate(rb_engine* e, const rb_config* c) {
+    if (has_data(c->uniforms)) {
+        const rb_uniforms* u = static_cast<const rb_uniforms*>(c->uniforms.ptr);
+        if (!(u->camera.pane_distance >= 0.0f && u->camera.pane_distance <= 100.0f))
+            return fail(e, RB_ERR_PANE_DISTANCE_OUT_OF_BOUNDS, "Pane-Distance is out of bounds");
+        if (!(u->camera.pane_width >= 0.0f && u->camera.pane_width <= 1000.0f))
+            return fail(e, RB_ERR_PANE_WIDTH_OUT_OF_BOUNDS, "Pane-Distance is out of bounds");  // sic, :631-633
+        const float* d = u->camera.dir;
+        const float len_sq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (len_sq < 1.1920929e-07f) return fail(e, RB_ERR_INVALID_CAMERA_DIRECTION, "Invalid camera direction");
+    } else if (c->uniforms.change == RB_DELETE) {
+        return fail(e, RB_ERR_CANNOT_DELETE_NONEXISTENT, "Cannot delete none existent");
+    }
+    if (has_data(c->spheres)) {
+        const rb_sphere* s = static_cast<const rb_sphere*>(c->spheres.ptr);
+        for (size_t i = 0; i < c->spheres.count; ++i)
+            if (s[i].radius <= 0.0f) return fail(e, RB_ERR_INVALID_SPHERES, "Invalid Spheres");
+    }
+    if (has_data(c->uvs)) {
+        if (c->uvs.count % 2 != 0) return fail(e, RB_ERR_INVALID_UVS, "Invalid UVs");
+    } else if (c->uvs.change == RB_DELETE) {
+        return fail(e, RB_ERR_UNSUPPORTED_DELETE, "not yet implemented: Implement UVs Deletion");
+    }
+    if (c->meshes.change == RB_DELETE)
+        return fail(e, RB_ERR_UNSUPPORTED_DELETE, "not yet implemented: Implement meshes Deletion");
+    if (has_data(c->lights)) {
+        const rb_point_light* l = static_cast<const rb_point_light*>(c->lights.ptr);
+        for (size_t i = 0; i < c->lights.count; ++i)
+            if (l[i].radius <= 0.0f) return fail(e, RB_ERR_INVALID_LIGHTS, "Invalid Lights");
+    } else if (c->lights.change == RB_DELETE) {
+        return fail(e, RB_ERR_UNSUPPORTED_DELETE, "not yet implemented: Implement lights Deletion");
+    }
+    if (c->textures.change == RB_DELETE)
+        return fail(e, RB_ERR_UNSUPPORTED_DELETE, "not yet implemented: Implement textures Deletion");
+    return RB_OK;
+}
+
+// create_storage_buffer -- buffers.rs:232-249: an empty slice still allocates one
+// zero-filled element (wgpu zero-initialises), so arrayLength() is 1.
+template <typename T>
+int upload(rb_engine* e, DevBuf<T>& buf, const void* src, size_t count, uint32_t* visible_len, bool pad_empty) {
+    const size_t alloc = (count == 0 && pad_empty) ? 1 : count;
+    HIP_TRY(e, buf.resize(alloc));
+    if (count > 0) {
+        HIP_TRY(e, hipMemcpyAsync(buf.ptr, src, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    } else if (alloc > 0) {
+        HIP_TRY(e, hipMemsetAsync(buf.ptr, 0, alloc * sizeof(T), e->stream));
+    }
+    if (visible_len) *visible_len = static_cast<uint32_t>(alloc);
+    return RB_OK;
+}
+
+// grow_resolution -- buffers.rs:171-180 (+ the stripe geometry of the sharded case)
+int resize_frame(rb_engine* e, uint32_t w, uint32_t h) {
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
+    uint32_t local = h, padded = h;
+    if (sc > 1) {
+        const uint32_t stripes = (h + sr - 1) / sr;
+        const uint32_t per_rank = (stripes + sc - 1) / sc;  // equal on every rank (padded)
+        padded = per_rank * sr;
+        uint32_t owned = 0;  // stripes this rank renders
+        for (uint32_t s = e->opt.shard_rank; s < stripes; s += sc) owned++;
+        local = owned * sr;  // the kernels additionally bound rows by global y < height
+    }
+    const uint64_t px = static_cast<uint64_t>(w) * padded;
+    if (px >= (1ull << 31)) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame of %u x %u pixels is too large", w, h);
+    HIP_TRY(e, e->accum.resize(px * 4));
+    HIP_TRY(e, e->out_rgba.resize(px));
+    if (px) {
+        HIP_TRY(e, hipMemsetAsync(e->accum.ptr, 0, px * 16, e->stream));
+        HIP_TRY(e, hipMemsetAsync(e->out_rgba.ptr, 0, px * 4, e->stream));
+    }
+    e->width = w;
+    e->height = h;
+    e->local_rows = local;
+    e->padded_rows = padded;
+    return RB_OK;
+}
+
+int upload_textures(rb_engine* e, const rb_field& f) {
+    const rb_texture* t = static_cast<const rb_texture*>(f.ptr);
+    std::vector<uint32_t> data;
+    std::vector<rb_texture_info> info;
+    uint32_t offset = 0;
+    for (size_t i = 0; i < f.count; ++i) {  // process_textures, buffers.rs:151-168
+        const size_t n = static_cast<size_t>(t[i].width) * t[i].height;
+        if (n > 0 && !t[i].rgba_data) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu has no data", i);
+        if (t[i].width == 0 || t[i].height == 0) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu is empty", i);
+        info.push_back(rb_texture_info{offset, t[i].width, t[i].height, 0});
+        data.insert(data.end(), t[i].rgba_data, t[i].rgba_data + n);
+        offset += t[i].width * t[i].height;
+    }
+    int rc = upload(e, e->tex_data, data.data(), data.size(), nullptr, true);
+    if (rc) return rc;
+    rc = upload(e, e->tex_info, info.data(), info.size(), nullptr, true);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));  // `data`/`info` are locals
+    e->n_tex = static_cast<uint32_t>(f.count);
+    return RB_OK;
+}
+
+// Applies one non-uniform field.  `first` = the engine's first update
+// (gpu_wrapper.rs:117-163: only Create is acted on); otherwise :196-294.
+int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
+    const bool bvh_field = (idx >= 5 && idx <= 7);
+    bool take = false, del = false;
+    if (first) {
+        take = (f.change == RB_CREATE);
+    } else {
+        if (f.change == RB_UPDATE) take = true;
+        else if (f.change == RB_DELETE) del = true;
+        else if (f.change == RB_CREATE) take = bvh_field;  // "Create not allowed after initialization" except BVH (:242-280)
+    }
+    if (!take && !del) return RB_OK;
+    const void* src = del ? nullptr : f.ptr;
+    const size_t n = del ? 0 : f.count;
+    int rc = RB_OK;
+    switch (idx) {
+        case 1: rc = upload(e, e->spheres, src, n, nullptr, true); e->n_spheres = static_cast<uint32_t>(n); break;
+        case 2: rc = upload(e, e->uvs, src, n, nullptr, true); e->n_uvs = static_cast<uint32_t>(n); break;
+        case 3: rc = upload(e, e->meshes, src, n, nullptr, true); e->n_meshes = static_cast<uint32_t>(n); break;
+        case 4:
+            // delete_lights creates a 4-byte buffer (buffers.rs:389-391): arrayLength() == 0
+            rc = upload(e, e->lights, src, n, &e->n_lights, !del);
+            if (del) e->n_lights = 0;
+            break;
+        case 5:
+            rc = upload(e, e->nodes, src, n, nullptr, true);
+            e->n_nodes = static_cast<uint32_t>(n);
+            e->host_nodes.assign(static_cast<const rb_bvh_node*>(src), static_cast<const rb_bvh_node*>(src) + n);
+            e->prep_dirty = true;
+            break;
+        case 6: rc = upload(e, e->indices, src, n, &e->n_indices, true); e->prep_dirty = true; break;
+        case 7: rc = upload(e, e->tris, src, n, nullptr, true); e->n_tris = static_cast<uint32_t>(n); e->prep_dirty = true; break;
+        case 8:
+            if (del) { rb_field empty{RB_UPDATE, nullptr, 0}; rc = upload_textures(e, empty); }
+            else rc = upload_textures(e, f);
+            break;
+        default: break;
+    }
+    return rc;
+}
+
+// Host-side checks that stand in for WGSL's robust buffer access: anything that
+// would make a HIP kernel read out of bounds or loop forever is refused here.
+int validate_scene(rb_engine* e, const rb_config* cfg) {
+    std::string why;
+    uint32_t depth = 0;
+    if (has_data(cfg->bvh_triangles)) {
+        const rb_gpu_triangle* t = static_cast<const rb_gpu_triangle*>(cfg->bvh_triangles.ptr);
+        uint32_t mx = 0;
+        for (size_t i = 0; i < cfg->bvh_triangles.count; ++i) mx = std::max(mx, t[i].mesh_index);
+        e->max_mesh_index = mx;
+    }
+    const uint32_t n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+    if (n_nodes > 0) {
+        if (!rb::bvh_validate(e->host_nodes.data(), n_nodes, rb::kStackDepth, why, &depth))
+            return fail(e, RB_ERR_INVALID_BVH, "%s", why.c_str());
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const rb_bvh_node& n = e->host_nodes[i];
+            if (n.primitive_count > 0 &&
+                static_cast<uint64_t>(n.first_primitive) + n.primitive_count > e->n_indices)
+                return fail(e, RB_ERR_INVALID_BVH, "leaf %u covers [%u, +%u) of %u bvh_indices", i, n.first_primitive,
+                            n.primitive_count, e->n_indices);
+        }
+    }
+    if (e->n_tris > 0 && e->uniforms.color_hash_enabled == 0 && e->max_mesh_index >= e->n_meshes)
+        return fail(e, RB_ERR_INVALID_MESHES, "a triangle references mesh %u of %u", e->max_mesh_index, e->n_meshes);
+    return RB_OK;
+}
+
+void set_device(rb_engine* e) { (void)hipSetDevice(e->device); }
+
+int ensure_prepared(rb_engine* e) {
+    if (!e->prep_dirty) return RB_OK;
+    const uint32_t len = e->n_indices;  // arrayLength(&bvh_indices) >= 1
+    HIP_TRY(e, e->ptris.resize(len));
+    HIP_TRY(e, e->pshade.resize(len));
+    int rc = rb::launch_prep_tris(e->tris.ptr, e->n_tris, e->indices.ptr, len, e->ptris.ptr, e->pshade.ptr, e->stream);
+    if (rc) return fail(e, RB_ERR_DEVICE, "prep kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    e->prep_dirty = false;
+    return RB_OK;
+}
+
+rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
+    rb::KParams p{};
+    p.u = e->uniforms;
+    // update_uniforms count patch-up -- gpu_wrapper.rs:475-495.  Keep leaves the caller's
+    // value; it is clamped to the buffer so a stale count cannot read out of bounds.
+    auto patch = [](uint32_t change, uint32_t given, uint32_t len) -> uint32_t {
+        if (change == RB_CREATE || change == RB_UPDATE) return len;
+        if (change == RB_DELETE) return 0u;
+        return std::min(given, len);
+    };
+    p.u.spheres_count = patch(e->last_change_spheres, e->uniforms.spheres_count, e->n_spheres);
+    p.u.bvh_node_count = patch(e->last_change_nodes, e->uniforms.bvh_node_count, e->n_nodes);
+    p.u.bvh_triangle_count = patch(e->last_change_tris, e->uniforms.bvh_triangle_count, e->n_tris);
+    p.spheres = e->spheres.ptr;
+    p.lights = e->lights.ptr;
+    p.meshes = e->meshes.ptr;
+    p.nodes = e->nodes.ptr;
+    p.indices = e->indices.ptr;
+    p.tris = e->tris.ptr;
+    p.ptris = e->ptris.ptr;
+    p.pshade = e->pshade.ptr;
+    p.uvs = e->uvs.ptr;
+    p.tex_data = e->tex_data.ptr;
+    p.tex_info = e->tex_info.ptr;
+    p.srgb_lut = e->srgb_lut.ptr;
+    p.accum = e->accum.ptr;
+    p.out_rgba = e->out_rgba.ptr;
+    p.counters = e->counters.ptr;
+    p.queue = e->queue.ptr;
+    p.n_lights = e->n_lights;
+    p.n_meshes = e->n_meshes;
+    p.index_len = e->n_indices;
+    p.n_uvs = e->n_uvs;
+    p.n_tex = e->n_tex;
+    p.first_pass = first_pass;
+    p.n_passes = n_passes;
+    p.samples_per_pass = e->prh.samples_per_pass;
+    p.shard_rank = e->opt.shard_rank;
+    p.shard_count = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    p.stripe_rows = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
+    p.local_rows = e->local_rows;
+    return p;
+}
+
+int require_ready(rb_engine* e) {
+    if (!e->initialized) return fail(e, RB_ERR_NOT_INITIALIZED, "engine has not received its first update");
+    if (!e->have_uniforms) return fail(e, RB_ERR_UNIFORMS_NOT_INITIALIZED, "Uniforms must be initialized");
+    return RB_OK;
+}
+
+int clear_accum(rb_engine* e) {
+    const size_t px = static_cast<size_t>(e->width) * e->padded_rows;
+    if (px) HIP_TRY(e, hipMemsetAsync(e->accum.ptr, 0, px * 16, e->stream));
+    return RB_OK;
+}
+
+// dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400.
+// The bvh_node_count patched for Keep is only known after make_params.
+int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
+    int rc = ensure_prepared(e);
+    if (rc) return rc;
+    if (n_passes == 0 || e->width == 0 || e->local_rows == 0) return RB_OK;
+    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_QUEUE;
+    const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
+    uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
+    HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
+    uint32_t launches = 0;
+    for (uint32_t done = 0; done < n_passes;) {
+        const uint32_t n = std::min(chunk, n_passes - done);
+        rb::KParams p = make_params(e, first_pass + done, n);
+        rb::LaunchInfo li{};
+        rc = rb::launch_render(p, kernel, stats, e->stream, &li);
+        if (rc) return fail(e, RB_ERR_DEVICE, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+        done += n;
+        launches++;
+    }
+    HIP_TRY(e, hipEventRecord(e->ev_end, e->stream));
+    e->last_launches = launches;
+    e->timing_pending = true;
+    e->stats.launches += launches;
+    return RB_OK;
+}
+
+int read_rgba(rb_engine* e, uint8_t* out) {
+    if (!out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    const size_t row_bytes = static_cast<size_t>(e->width) * 4;
+    if (sc == 1) {
+        HIP_TRY(e, hipMemcpyAsync(out, e->out_rgba.ptr, row_bytes * e->height, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        HIP_TRY(e, hipMemcpyAsync(out, e->out_rgba.ptr, row_bytes * e->padded_rows, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RB_OK;
+}
+
+int accumulate_timing(rb_engine* e) {
+    float ms = 0.0f;
+    if (e->last_launches > 0) {
+        HIP_TRY(e, hipEventSynchronize(e->ev_end));
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_begin, e->ev_end));
+    }
+    e->last_dispatch_ms = ms;
+    if (e->timing_pending) {
+        e->stats.kernel_ms += ms;
+        e->timing_pending = false;
+    }
+    return RB_OK;
+}
+
+int update_locked(rb_engine* e, const rb_config* cfg) {
+    int rc = check_fields(e, cfg);
+    if (rc) return rc;
+    const bool first = !e->initialized;
+    rc = first ? validate_init(e, cfg) : validate(e, cfg);
+    if (rc) return rc;
+
+    // ---- uniforms (gpu_wrapper.rs:122-136 / :165-192)
+    const bool take_uniforms = first ? (cfg->uniforms.change == RB_CREATE) : (cfg->uniforms.change == RB_UPDATE);
+    if (take_uniforms) {
+        const rb_uniforms* u = static_cast<const rb_uniforms*>(cfg->uniforms.ptr);
+        if (u->width != e->width || u->height != e->height || e->accum.ptr == nullptr) {
+            rc = resize_frame(e, u->width, u->height);
+            if (rc) return rc;
+        }
+        e->uniforms = *u;
+        e->prh.total_samples = u->total_samples;  // ProgressiveRenderHelper::update (:47-52)
+        e->prh.total_passes = (u->total_samples + e->prh.samples_per_pass - 1) / e->prh.samples_per_pass;
+    }
+    // self.rc = new_rc (:298): width()/height()/update_uniforms panic unless the *latest*
+    // config carried Create/Update uniforms (:303-329,470-473).
+    e->have_uniforms = has_data(cfg->uniforms);
+
+    for (int i = 1; i < 9; ++i) {
+        rc = apply_field(e, i, *field_at(cfg, i), first);
+        if (rc) return rc;
+    }
+    e->last_change_spheres = cfg->spheres.change;
+    e->last_change_nodes = cfg->bvh_nodes.change;
+    e->last_change_tris = cfg->bvh_triangles.change;
+    rc = validate_scene(e, cfg);
+    if (rc) return rc;
+    e->initialized = true;
+    // inputs are borrowed only for this call.  (Without Create/Update uniforms the reference
+    // panics at the next use, gpu_wrapper.rs:303-329; here that is require_ready's error.)
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RB_OK;
+}
+
+int render_locked(rb_engine* e, uint8_t* rgba_out) {
+    int rc = require_ready(e);
+    if (rc) return rc;
+    if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    rc = clear_accum(e);  // dispatch_compute, gpu_wrapper.rs:407-411
+    if (rc) return rc;
+    e->prh.current_pass = 0;
+    rc = dispatch(e, 0, e->prh.total_passes);
+    if (rc) return rc;
+    e->prh.current_pass = e->prh.total_passes ? e->prh.total_passes - 1 : 0;  // loop variable's last value (:415)
+    rc = read_rgba(e, rgba_out);
+    if (rc) return rc;
+    return accumulate_timing(e);
+}
+
+rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
+    g_create_error.clear();
+    if (!cfg) { fail(nullptr, RB_ERR_NULL_ARGUMENT, "config is NULL"); return nullptr; }
+    if (check_fields(nullptr, cfg)) return nullptr;
+    // GpuBuffers::new panics unless these are Create (buffers.rs:74-97)
+    if (validate_init(nullptr, cfg)) return nullptr;
+    rb_options opt{};
+    opt.device = -1;
+    if (opt_in) opt = *opt_in;
+    if (opt.shard_count > 1 && opt.shard_rank >= opt.shard_count) {
+        fail(nullptr, RB_ERR_INVALID_OPTIONS, "shard_rank %u >= shard_count %u", opt.shard_rank, opt.shard_count);
+        return nullptr;
+    }
+    if (opt.kernel > RB_KERNEL_QUEUE) { fail(nullptr, RB_ERR_INVALID_OPTIONS, "unknown kernel %u", opt.kernel); return nullptr; }
+    int dev = opt.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) { fail(nullptr, RB_ERR_DEVICE, "no HIP device available"); return nullptr; }
+    }
+    if (hipSetDevice(dev) != hipSuccess) { fail(nullptr, RB_ERR_DEVICE, "hipSetDevice(%d) failed", dev); return nullptr; }
+    rb_engine* e = new rb_engine();
+    e->device = dev;
+    e->opt = opt;
+    auto bail = [&](const char* what, hipError_t st) -> rb_engine* {
+        fail(nullptr, RB_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(st));
+        delete e;
+        return nullptr;
+    };
+    hipError_t st;
+    if ((st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", st);
+    if ((st = hipEventCreate(&e->ev_begin)) != hipSuccess) return bail("hipEventCreate", st);
+    if ((st = hipEventCreate(&e->ev_end)) != hipSuccess) return bail("hipEventCreate", st);
+    if ((st = e->counters.resize(rb::C_COUNT)) != hipSuccess) return bail("hipMalloc(counters)", st);
+    if ((st = e->queue.resize(4)) != hipSuccess) return bail("hipMalloc(queue)", st);
+    if ((st = hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream)) != hipSuccess)
+        return bail("hipMemset(counters)", st);
+    // sRGB -> linear table for sample_texture's pow(c, 2.2) (shader.wgsl:185-190)
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = powf(static_cast<float>(i) / 255.0f, 2.2f);
+    if ((st = e->srgb_lut.resize(256)) != hipSuccess) return bail("hipMalloc(lut)", st);
+    if ((st = hipMemcpy(e->srgb_lut.ptr, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(lut)", st);
+    // ProgressiveRenderHelper::new (gpu_wrapper.rs:38-45); SAMPLES_PER_PASS = 1 (:12)
+    const rb_uniforms* u = static_cast<const rb_uniforms*>(cfg->uniforms.ptr);
+    e->prh.samples_per_pass = 1;
+    e->prh.total_samples = u->total_samples;
+    e->prh.total_passes = u->total_samples;
+    e->prh.current_pass = 0;
+    return e;
+}
+
+}  // namespace
+
+// ============================================================== C ABI ======
+extern "C" {
+
+rb_engine* rb_create(const rb_config* cfg) { return create_impl(cfg, nullptr); }
+rb_engine* rb_create_ex(const rb_config* cfg, const rb_options* opt) { return create_impl(cfg, opt); }
+
+void rb_destroy(rb_engine* e) {
+    if (!e) return;
+    set_device(e);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
+    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* rb_last_error(const rb_engine* e) { return e ? e->error.c_str() : g_create_error.c_str(); }
+
+int rb_update(rb_engine* e, const rb_config* cfg) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    return update_locked(e, cfg);
+}
+
+int rb_render(rb_engine* e, uint8_t* rgba_out) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    return render_locked(e, rgba_out);
+}
+
+int rb_render_config(rb_engine* e, const rb_config* cfg, uint8_t* rgba_out) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = update_locked(e, cfg);
+    if (rc) return rc;
+    return render_locked(e, rgba_out);
+}
+
+int rb_iter_begin(rb_engine* e, const rb_config* cfg) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = update_locked(e, cfg);
+    if (rc) return rc;
+    rc = require_ready(e);
+    if (rc) return rc;
+    e->prh.current_pass = 0;       // lib.rs:91
+    e->iter_initialized = false;   // RaytracerFrameIterator::new (lib.rs:144-150)
+    return RB_OK;
+}
+
+int rb_iter_has_next(rb_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lock(e->mu);
+    return e->prh.current_pass < e->prh.total_passes ? 1 : 0;  // lib.rs:153-156
+}
+
+int rb_iter_next(rb_engine* e, uint8_t* rgba_out) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    if (!(e->prh.current_pass < e->prh.total_passes))
+        return fail(e, RB_ERR_NO_MORE_FRAMES, "No more frames available");  // lib.rs:170-177
+    int rc = require_ready(e);
+    if (rc) return rc;
+    if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    if (!e->iter_initialized) {  // lib.rs:181-192
+        rc = clear_accum(e);
+        if (rc) return rc;
+        e->iter_initialized = true;
+    }
+    rc = dispatch(e, e->prh.current_pass, 1);  // lib.rs:200-203
+    if (rc) return rc;
+    rc = read_rgba(e, rgba_out);  // lib.rs:205
+    if (rc) return rc;
+    e->prh.current_pass += 1;  // lib.rs:213
+    return accumulate_timing(e);
+}
+
+void rb_iter_destroy(rb_engine* e) { (void)e; }  // lib.rs:231-233: logs only
+
+int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    if (!e->have_uniforms) return RB_ERR_UNIFORMS_NOT_INITIALIZED;
+    if (width) *width = e->width;
+    if (height) *height = e->height;
+    return RB_OK;
+}
+
+int rb_clear(rb_engine* e) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = require_ready(e);
+    if (rc) return rc;
+    return clear_accum(e);
+}
+
+int rb_dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = require_ready(e);
+    if (rc) return rc;
+    return dispatch(e, first_pass, n_passes);
+}
+
+int rb_sync(rb_engine* e) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RB_OK;
+}
+
+int rb_read_rgba(rb_engine* e, uint8_t* rgba_out) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = require_ready(e);
+    if (rc) return rc;
+    return read_rgba(e, rgba_out);
+}
+
+int rb_read_accumulation(rb_engine* e, float* accum_out) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = require_ready(e);
+    if (rc) return rc;
+    if (!accum_out) return fail(e, RB_ERR_NULL_ARGUMENT, "accum_out is NULL");
+    const uint32_t rows = (e->opt.shard_count > 1) ? e->padded_rows : e->height;
+    HIP_TRY(e, hipMemcpyAsync(accum_out, e->accum.ptr, static_cast<size_t>(e->width) * rows * 16, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RB_OK;
+}
+
+int rb_device_rgba(rb_engine* e, void** d_ptr, size_t* bytes) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (d_ptr) *d_ptr = e->out_rgba.ptr;
+    if (bytes) *bytes = static_cast<size_t>(e->width) * e->padded_rows * 4;
+    return RB_OK;
+}
+
+int rb_local_rows(const rb_engine* e, uint32_t* rows, uint32_t* padded_rows) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
+    uint32_t owned = e->height;
+    if (sc > 1) {
+        owned = 0;
+        const uint32_t stripes = (e->height + sr - 1) / sr;
+        for (uint32_t s = e->opt.shard_rank; s < stripes; s += sc) owned += std::min(sr, e->height - s * sr);
+    }
+    if (rows) *rows = owned;
+    if (padded_rows) *padded_rows = e->padded_rows;
+    return RB_OK;
+}
+
+int rb_global_row(const rb_engine* e, uint32_t local_row, uint32_t* global_row) {
+    if (!e || !global_row) return RB_ERR_NULL_ARGUMENT;
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
+    if (sc == 1) { *global_row = local_row; return RB_OK; }
+    *global_row = ((local_row / sr) * sc + e->opt.shard_rank) * sr + local_row % sr;
+    return RB_OK;
+}
+
+int rb_get_stats(rb_engine* e, rb_stats* out) {
+    if (!e || !out) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    unsigned long long c[rb::C_COUNT];
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(c, e->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    e->stats.segments = c[rb::C_SEGMENTS];
+    e->stats.paths = c[rb::C_PATHS];
+    e->stats.nodes_popped = c[rb::C_NODES];
+    e->stats.tris_tested = c[rb::C_TRIS];
+    e->stats.spheres_tested = c[rb::C_SPHERES];
+    e->stats.lights_tested = c[rb::C_LIGHTS];
+    e->stats.mesh_hits = c[rb::C_MESH_HITS];
+    *out = e->stats;
+    return RB_OK;
+}
+
+int rb_reset_stats(rb_engine* e) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    HIP_TRY(e, hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream));
+    e->stats = rb_stats{};
+    return RB_OK;
+}
+
+int rb_last_dispatch_ms(rb_engine* e, float* ms) {
+    if (!e || !ms) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    int rc = accumulate_timing(e);
+    if (rc) return rc;
+    *ms = e->last_dispatch_ms;
+    return RB_OK;
+}
+
+int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris, rb_bvh_node* nodes_out, size_t nodes_capacity,
+                 size_t* n_nodes, uint32_t* indices_out) {
+    if (!n_nodes || (n_tris > 0 && !tris)) return RB_ERR_NULL_ARGUMENT;
+    std::vector<rb_bvh_node> nodes;
+    std::vector<uint32_t> indices;
+    rb::bvh_build(tris, n_tris, nodes, indices);
+    *n_nodes = nodes.size();
+    if (!nodes_out) return RB_OK;
+    if (nodes_capacity < nodes.size()) return RB_ERR_INVALID_BVH;
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(rb_bvh_node));
+    if (indices_out) std::memcpy(indices_out, indices.data(), indices.size() * sizeof(uint32_t));
+    return RB_OK;
+}
+
+const char* rb_version(void) { return "renderbaby-hip 0.1 (gfx950)"; }
+
+int rb_device_name(int device, char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return RB_ERR_NULL_ARGUMENT;
+    hipDeviceProp_t prop;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return RB_ERR_DEVICE;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RB_ERR_DEVICE;
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return RB_OK;
+}
+
+// Debug hook for tests/test_gpu_math.py: device /, sqrt, normalize, u32->f32, min/max, dot.
+int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n) {
+    if (!a || !b || !out8n) return RB_ERR_NULL_ARGUMENT;
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&da), n * 4) != hipSuccess) return RB_ERR_DEVICE;
+    if (hipMalloc(reinterpret_cast<void**>(&db), n * 4) != hipSuccess) return RB_ERR_DEVICE;
+    if (hipMalloc(reinterpret_cast<void**>(&dout), static_cast<size_t>(n) * 32) != hipSuccess) return RB_ERR_DEVICE;
+    (void)hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+    int rc = rb::launch_debug_math(da, db, dout, n, nullptr);
+    hipError_t st = hipDeviceSynchronize();
+    (void)hipMemcpy(out8n, dout, static_cast<size_t>(n) * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return (rc || st != hipSuccess) ? RB_ERR_DEVICE : RB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's renderer interface over the C ABI.
+
+Names and semantics follow the reference so parity tests read like its own code:
+
+* ``Change`` / ``RenderConfig`` / ``RenderConfigBuilder`` --
+  crates/engine-config/src/render_config.rs:37-57,99-109,312-606
+* ``Engine.new(rc)`` / ``Engine.render(rc)`` / ``Engine.frame_iterator(rc)`` --
+  ``impl Renderer for Engine``, crates/engine-pathtracer/src/lib.rs:58-119
+* ``Frame`` / ``FrameIterator.has_next/next/destroy`` --
+  crates/frame-buffer/src/frame_iterator.rs:3-51
+
+Everything that computes is in librenderbaby_hip.so; this file only marshals.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, List, Optional
+
+import numpy as np
+
+from . import abi
+from ._lib import load
+
+
+class RenderError(RuntimeError):
+    """anyhow::Error of the reference; ``code`` is the rb_abi.h status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[{abi.ERR.get(code, code)}] {message}")
+        self.code = code
+        self.message = message
+
+
+@dataclass
+class Change:
+    """``enum Change<T> { Keep, Create(T), Update(T), Delete }``"""
+    tag: int
+    value: Any = None
+
+    @staticmethod
+    def keep():
+        return Change(abi.KEEP)
+
+    @staticmethod
+    def create(v):
+        return Change(abi.CREATE, v)
+
+    @staticmethod
+    def update(v):
+        return Change(abi.UPDATE, v)
+
+    @staticmethod
+    def delete():
+        return Change(abi.DELETE)
+
+
+_FIELDS = ("uniforms", "spheres", "uvs", "meshes", "lights", "bvh_nodes", "bvh_indices", "bvh_triangles",
+           "textures")
+_DTYPES = {"uniforms": abi.UNIFORMS, "spheres": abi.SPHERE, "uvs": np.float32, "meshes": abi.MESH,
+           "lights": abi.POINT_LIGHT, "bvh_nodes": abi.BVH_NODE, "bvh_indices": np.uint32,
+           "bvh_triangles": abi.GPU_TRIANGLE}
+
+
+class RenderConfig:
+    """``struct RenderConfig`` -- nine ``Change`` fields, default Keep."""
+
+    def __init__(self, **kw):
+        for f in _FIELDS:
+            setattr(self, f, kw.get(f, Change.keep()))
+
+    @staticmethod
+    def builder():
+        return RenderConfigBuilder()
+
+    @staticmethod
+    def from_scene(scene, create=True):
+        """What generate_full_render_command_builder emits
+        (scene_engine_adapter.rs:463-490): all ``*_create`` on the first render;
+        afterwards Update for everything except the three BVH fields, which stay Create."""
+        mk = Change.create if create else Change.update
+        return RenderConfig(
+            uniforms=mk(scene.uniforms), spheres=mk(scene.spheres), uvs=mk(scene.uvs), meshes=mk(scene.meshes),
+            lights=mk(scene.lights), bvh_nodes=Change.create(scene.bvh_nodes),
+            bvh_indices=Change.create(scene.bvh_indices), bvh_triangles=Change.create(scene.bvh_triangles),
+            textures=mk(scene.textures))
+
+    # ---- marshalling
+    def to_c(self):
+        """Returns (abi.Config, keepalive list)."""
+        cfg = abi.Config()
+        keep: List[Any] = []
+        for f in _FIELDS:
+            ch: Change = getattr(self, f)
+            fld = abi.Field()
+            fld.change = ch.tag
+            fld.ptr = None
+            fld.count = 0
+            if ch.tag in (abi.CREATE, abi.UPDATE):
+                if f == "textures":
+                    texs = ch.value or []
+                    arr = (abi.Texture * max(len(texs), 1))()
+                    for i, (w, h, data) in enumerate(texs):
+                        d = np.ascontiguousarray(data, dtype=np.uint32)
+                        keep.append(d)
+                        arr[i].width, arr[i].height, arr[i].rgba_data = int(w), int(h), d.ctypes.data
+                    keep.append(arr)
+                    fld.ptr = C.cast(arr, C.c_void_p).value if texs else None
+                    fld.count = len(texs)
+                else:
+                    a = np.ascontiguousarray(np.atleast_1d(ch.value), dtype=_DTYPES[f])
+                    keep.append(a)
+                    fld.ptr = a.ctypes.data if a.size else None
+                    fld.count = a.size
+            setattr(cfg, f, fld)
+        return cfg, keep
+
+
+class RenderConfigBuilder:
+    """``RenderConfigBuilder``: ``x(v)`` = Update, ``x_create(v)``, ``x_no_change()``, ``x_delete()``."""
+
+    def __init__(self):
+        self._rc = RenderConfig()
+
+    def build(self):
+        return self._rc
+
+
+def _add_builder_methods():
+    for f in _FIELDS:
+        def upd(self, v, _f=f):
+            setattr(self._rc, _f, Change.update(v))
+            return self
+
+        def cre(self, v, _f=f):
+            setattr(self._rc, _f, Change.create(v))
+            return self
+
+        def keep(self, _f=f):
+            setattr(self._rc, _f, Change.keep())
+            return self
+
+        def dele(self, _f=f):
+            setattr(self._rc, _f, Change.delete())
+            return self
+        setattr(RenderConfigBuilder, f, upd)
+        setattr(RenderConfigBuilder, f + "_create", cre)
+        setattr(RenderConfigBuilder, f + "_no_change", keep)
+        setattr(RenderConfigBuilder, f + "_delete", dele)
+
+
+_add_builder_methods()
+
+
+@dataclass
+class Frame:
+    """``struct Frame { width, height, pixels: Vec<u8> }`` (RGBA8, x mirrored, A = 255)."""
+    width: int
+    height: int
+    pixels: np.ndarray  # uint8, (height, width, 4)
+
+    def expected_size(self):
+        return self.width * self.height * 4
+
+    def validate(self):
+        if self.pixels.size != self.expected_size():
+            raise RenderError(0, f"Frame pixel size mismatch: expected {self.expected_size()} bytes, got {self.pixels.size}")
+
+
+class Engine:
+    """``engine_pathtracer::Engine`` for the HIP backend."""
+
+    def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False):
+        self._lib = load()
+        cfg, keep = rc.to_c()
+        opt = abi.Options()
+        opt.device = device
+        opt.shard_rank, opt.shard_count, opt.stripe_rows = shard_rank, shard_count, stripe_rows
+        opt.passes_per_launch = passes_per_launch
+        opt.kernel = kernel
+        opt.flags = abi.FLAG_STATS if stats else 0
+        self._h = self._lib.rb_create_ex(C.byref(cfg), C.byref(opt))
+        del keep
+        if not self._h:
+            msg = self._lib.rb_last_error(None)
+            raise RenderError(abi.ERR and 16, (msg or b"rb_create failed").decode())
+        self.shard_count = max(shard_count, 1)
+
+    @classmethod
+    def new(cls, rc, **kw):
+        return cls(rc, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != abi.RB_OK:
+            raise RenderError(rc, (self._lib.rb_last_error(self._h) or b"").decode())
+
+    # ---- Renderer
+    def update(self, rc: RenderConfig):
+        cfg, keep = rc.to_c()
+        self._check(self._lib.rb_update(self._h, C.byref(cfg)))
+        del keep
+
+    def size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.rb_get_size(self._h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def _frame_shape(self):
+        w, h = self.size()
+        if self.shard_count > 1:
+            h = self.local_rows()[1]
+        return w, h
+
+    def render(self, rc: RenderConfig) -> Frame:
+        cfg, keep = rc.to_c()
+        self._check(self._lib.rb_update(self._h, C.byref(cfg)))
+        del keep
+        w, h = self._frame_shape()
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self._lib.rb_render(self._h, out.ctypes.data))
+        return Frame(w, h, out)
+
+    def frame_iterator(self, rc: RenderConfig) -> "FrameIterator":
+        cfg, keep = rc.to_c()
+        self._check(self._lib.rb_iter_begin(self._h, C.byref(cfg)))
+        del keep
+        return FrameIterator(self)
+
+    # ---- lower-level control (bench, tests, multi-GPU)
+    def clear(self):
+        self._check(self._lib.rb_clear(self._h))
+
+    def dispatch(self, first_pass, n_passes):
+        self._check(self._lib.rb_dispatch(self._h, first_pass, n_passes))
+
+    def sync(self):
+        self._check(self._lib.rb_sync(self._h))
+
+    def read_rgba(self):
+        w, h = self._frame_shape()
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self._lib.rb_read_rgba(self._h, out.ctypes.data))
+        return out
+
+    def read_accumulation(self):
+        w, h = self._frame_shape()
+        out = np.empty((h, w, 4), dtype=np.float32)
+        self._check(self._lib.rb_read_accumulation(self._h, out.ctypes.data))
+        return out
+
+    def device_rgba(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.rb_device_rgba(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def local_rows(self):
+        r, pr = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.rb_local_rows(self._h, C.byref(r), C.byref(pr)))
+        return r.value, pr.value
+
+    def global_row(self, local_row):
+        g = C.c_uint32()
+        self._check(self._lib.rb_global_row(self._h, local_row, C.byref(g)))
+        return g.value
+
+    def stats(self):
+        s = abi.Stats()
+        self._check(self._lib.rb_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self._lib.rb_reset_stats(self._h))
+
+    def last_dispatch_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.rb_last_dispatch_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+class FrameIterator:
+    """``RaytracerFrameIterator`` (lib.rs:127-234)."""
+
+    def __init__(self, engine: Engine):
+        self._e = engine
+
+    def has_next(self) -> bool:
+        return bool(self._e._lib.rb_iter_has_next(self._e._h))
+
+    def next(self) -> Frame:
+        w, h = self._e._frame_shape()
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._e._check(self._e._lib.rb_iter_next(self._e._h, out.ctypes.data))
+        return Frame(w, h, out)
+
+    def destroy(self):
+        self._e._lib.rb_iter_destroy(self._e._h)
+
+    def __iter__(self):
+        while self.has_next():
+            yield self.next()
+
+
+def device_name(device=-1):
+    buf = C.create_string_buffer(256)
+    rc = load().rb_device_name(device, buf, 256)
+    return buf.value.decode() if rc == 0 else "unknown"

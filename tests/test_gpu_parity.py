@@ -1,0 +1,94 @@
+"""HIP path vs the CPU oracle on identical seeded inputs, through the C ABI.
+
+Bar: bit-exact on the f32 accumulation and on RGBA8 (integer/byte work and,
+because both sides perform the same IEEE binary32 operations in the same
+order, the floating-point work too).  Work counters must agree exactly.
+"""
+import numpy as np
+import pytest
+
+from renderbaby_amd import Engine, RenderConfig, abi, scenes
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [abi.KERNEL_PIXEL, abi.KERNEL_QUEUE]
+
+
+def _hip(scene, kernel, stats=True, **kw):
+    rc = RenderConfig.from_scene(scene)
+    eng = Engine.new(rc, kernel=kernel, stats=stats, **kw)
+    frame = eng.render(rc)
+    acc = eng.read_accumulation()
+    st = eng.stats()
+    eng.close()
+    return frame, acc, st
+
+
+def _assert_same(scene, kernel):
+    o_acc, _, o_rgba, o_st = _oracle.render(scene)
+    frame, acc, st = _hip(scene, kernel)
+    # shader x order for the accumulation, mirrored x for the frame
+    assert acc.shape == o_acc.shape
+    bad = np.argwhere(acc.view(np.uint32) != o_acc.view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} accumulation words differ, first {bad[:5]}: {acc[tuple(bad[0][:2])]} vs {o_acc[tuple(bad[0][:2])]}"
+    assert np.array_equal(frame.pixels, o_rgba)
+    for k in ("segments", "paths", "nodes_popped", "tris_tested", "spheres_tested", "lights_tested", "mesh_hits"):
+        assert st[k] == o_st[k], (k, st[k], o_st[k])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cornell_bit_exact(kernel):
+    _assert_same(scenes.cornell(96, 64, 8, 4), kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cornell_depth8_odd_size(kernel):
+    _assert_same(scenes.cornell(61, 37, 5, 8), kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("color_hash", [0, 1])
+def test_feature_scene_bit_exact(kernel, color_hash):
+    # ground + checkerboard, textured mesh and sphere, metal/mirror, two point lights, sky
+    _assert_same(scenes.feature_scene(48, 32, 6, 5, color_hash=color_hash), kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_mesh_bvh_bit_exact(kernel):
+    s = scenes.mesh_scene(24, 24, 64, 40, 4, 5, seed=7)  # 2304 triangles, multi-level BVH
+    assert len(s.bvh_nodes) > 1
+    _assert_same(s, kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sky_only_known_answer(kernel):
+    s = scenes.sky_only()
+    frame, acc, st = _hip(s, kernel)
+    assert np.all(frame.pixels == np.array([147, 164, 181, 255], dtype=np.uint8))
+    assert st["segments"] == s.width * s.height
+
+
+def test_device_math_is_ieee():
+    import ctypes as C
+    from renderbaby_amd._lib import load
+    rng = np.random.default_rng(1)
+    n = 1 << 16
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    b[b == 0] = 1.0
+    out = np.zeros((8, n), dtype=np.float32)
+    assert load().rb_debug_math(a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    with np.errstate(all="ignore"):
+        assert np.array_equal(out[0].view(np.uint32), (a / b).view(np.uint32)), "f32 division is not correctly rounded"
+        assert np.array_equal(out[1].view(np.uint32), np.sqrt(np.abs(a)).view(np.uint32)), "f32 sqrt is not correctly rounded"
+        z = (a * b).astype(np.float32)
+        ln = np.sqrt(((a * a + b * b).astype(np.float32) + z * z).astype(np.float32)).astype(np.float32)
+        for k, comp in enumerate((a, b, z)):
+            exp = (comp / ln).astype(np.float32)
+            ok = (out[2 + k].view(np.uint32) == exp.view(np.uint32)) | (np.isnan(exp) & np.isnan(out[2 + k]))
+            assert ok.all(), f"normalize component {k}"
+        exp = (a.view(np.uint32).astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+        assert np.array_equal(out[5].view(np.uint32), exp.view(np.uint32)), "u32->f32"
+        exp = ((a * b + b * b).astype(np.float32) + a * a).astype(np.float32)
+        assert np.array_equal(out[7].view(np.uint32), exp.view(np.uint32)), "dot: contraction or reassociation"

@@ -386,7 +386,7 @@ def checker_texture(w=8, h=4):
     return (w, h, (r | (g << 8) | (b << 16) | (255 << 24)).astype(np.uint32).reshape(-1))
 
 
-def feature_scene(width=48, height=32, spp=4, max_depth=5, color_hash=0, seed=3):
+def feature_scene(width=48, height=32, spp=4, max_depth=5, color_hash=0, seed=3, bvh_builder=None):
     """Exercises every live shader branch at test size: ground + checkerboard,
     textured mesh + textured sphere, lambert / fuzzy metal / mirror spheres,
     two point lights, emissive quad, sky."""
@@ -412,7 +412,7 @@ def feature_scene(width=48, height=32, spp=4, max_depth=5, color_hash=0, seed=3)
     u = make_uniforms(width, height, spp, max_depth, cam_pos=(0.2, 1.0, 4.0), cam_dir=(-0.05, -0.2, -1.0),
                       ground_enabled=1, ground_height=-1.0, checkerboard_enabled=1, sky=(0.5, 0.7, 1.0),
                       color_hash=color_hash, cb1=(0.05, 0.05, 0.05), cb2=(1.0, 0.0, 1.0))
-    return _finish("feature", u, sp, lights, tri_groups, uv_groups, [tex])
+    return _finish("feature", u, sp, lights, tri_groups, uv_groups, [tex], bvh_builder=bvh_builder)
 
 
 def sky_only(width=16, height=8, spp=1, sky=(0.5, 0.7, 1.0)):

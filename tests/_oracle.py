@@ -73,6 +73,19 @@ def lib():
     return _lib
 
 
+STAT_KEYS = ("segments", "paths", "nodes_popped", "tris_tested", "spheres_tested", "lights_tested", "mesh_hits")
+
+
+def load_golden(path):
+    """-> (Scene, accum, rgba, stats dict) from a tests/golden/*.npz fixture."""
+    from renderbaby_amd import scenes
+    z = np.load(path)
+    texs = [(int(z[f"tex{i}_wh"][0]), int(z[f"tex{i}_wh"][1]), z[f"tex{i}_data"]) for i in range(int(z["n_textures"]))]
+    sc = scenes.Scene(z["uniforms"], z["spheres"], z["lights"], z["meshes"], z["bvh_nodes"], z["bvh_indices"],
+                      z["bvh_triangles"], z["uvs"], texs, name=os.path.basename(path))
+    return sc, z["accum"], z["rgba"], dict(zip(STAT_KEYS, (int(v) for v in z["stats"])))
+
+
 def _f3(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
@@ -142,3 +155,38 @@ def bvh_build(tris):
     idx = np.zeros(len(tris), dtype=np.uint32)
     assert L.rbo_bvh_build(tris.ctypes.data, len(tris), nodes.ctypes.data, len(nodes), C.byref(n), idx.ctypes.data) == 0
     return nodes, idx
+
+
+# ---- small wrappers that keep their float32 temporaries alive across the call
+def isect_sphere(o, d, c, r):
+    o, d, c = _f3(o), _f3(d), _f3(c)
+    return lib().rbo_intersect_sphere(o.ctypes.data, d.ctypes.data, c.ctypes.data, r)
+
+
+def isect_triangle(o, d, v0, v1, v2):
+    o, d, v0, v1, v2 = _f3(o), _f3(d), _f3(v0), _f3(v1), _f3(v2)
+    u, v = C.c_float(), C.c_float()
+    t = lib().rbo_intersect_triangle(o.ctypes.data, d.ctypes.data, v0.ctypes.data, v1.ctypes.data, v2.ctypes.data,
+                                     C.byref(u), C.byref(v))
+    return t, u.value, v.value
+
+
+def isect_aabb(o, d, mn, mx):
+    o, d, mn, mx = _f3(o), _f3(d), _f3(mn), _f3(mx)
+    return lib().rbo_intersect_aabb(o.ctypes.data, d.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+
+
+def isect_ground(o, d, gh):
+    o, d = _f3(o), _f3(d)
+    return lib().rbo_intersect_ground(o.ctypes.data, d.ctypes.data, gh)
+
+
+def color_map(rgb):
+    rgb = _f3(rgb)
+    return lib().rbo_color_map(rgb.ctypes.data)
+
+
+def hash_to_color(n):
+    rgb = np.zeros(3, np.float32)
+    lib().rbo_hash_to_color(n, rgb.ctypes.data)
+    return rgb

@@ -1,0 +1,69 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol that
+include/rb_abi.h declares; POD layouts match the reference's #[repr(C)] types."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from renderbaby_amd import abi
+from renderbaby_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_layout_sizes_and_offsets():
+    # sizes 144/48/80/96/96/96/48/64 and the field offsets
+    assert abi.UNIFORMS.itemsize == 144 and abi.CAMERA.itemsize == 48 and abi.MATERIAL.itemsize == 80
+    assert abi.SPHERE.itemsize == abi.POINT_LIGHT.itemsize == abi.MESH.itemsize == 96
+    assert abi.BVH_NODE.itemsize == 48 and abi.GPU_TRIANGLE.itemsize == 64
+    off = {n: abi.UNIFORMS.fields[n][1] for n in abi.UNIFORMS.names}
+    assert (off["width"], off["height"], off["total_samples"], off["color_hash_enabled"], off["camera"]) == (0, 4, 8, 12, 16)
+    assert (off["spheres_count"], off["triangles_count"], off["bvh_node_count"], off["bvh_triangle_count"], off["bvh_root"]) == (64, 68, 72, 76, 80)
+    assert (off["ground_height"], off["ground_enabled"], off["checkerboard_enabled"], off["sky_color"], off["max_depth"]) == (84, 88, 92, 96, 108)
+    assert (off["checkerboard_color_1"], off["checkerboard_color_2"]) == (112, 128)
+    cam = {n: abi.CAMERA.fields[n][1] for n in abi.CAMERA.names}
+    assert (cam["pane_distance"], cam["pane_width"], cam["pos"], cam["dir"]) == (0, 4, 16, 32)
+    m = {n: abi.MATERIAL.fields[n][1] for n in abi.MATERIAL.names}
+    assert (m["ambient"], m["diffuse"], m["specular"], m["shininess"], m["emissive"], m["ior"], m["opacity"], m["illum"], m["texture_index"]) == (0, 16, 32, 44, 48, 60, 64, 68, 72)
+    n = {k: abi.BVH_NODE.fields[k][1] for k in abi.BVH_NODE.names}
+    assert (n["aabb_min"], n["aabb_max"], n["left"], n["right"], n["first_primitive"], n["primitive_count"]) == (0, 16, 32, 36, 40, 44)
+    t = {k: abi.GPU_TRIANGLE.fields[k][1] for k in abi.GPU_TRIANGLE.names}
+    assert (t["v0"], t["v0_index"], t["v1"], t["v1_index"], t["v2"], t["v2_index"], t["mesh_index"]) == (0, 12, 16, 28, 32, 44, 48)
+    assert C.sizeof(abi.Field) == 24 and C.sizeof(abi.Config) == 9 * 24
+    assert C.sizeof(abi.Options) == 48 and C.sizeof(abi.Stats) == 72
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rb_abi.h")).read()
+    declared = set(re.findall(r"\b(rb_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()  # links against libamdhip64; must load without a GPU
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in rb_abi.h but not exported: {missing}"
+    assert set(_lib.EXPORTS) <= declared
+    assert b"gfx950" in lib.rb_version()
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "rb_abi.h"\nint main(void){return sizeof(rb_uniforms)==144?0:1;}\n')
+    for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++17")):
+        exe = tmp_path / ("t_" + cc)
+        subprocess.check_call([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        assert subprocess.call([str(exe)]) == 0
+
+
+def test_create_rejects_non_create_fields_without_touching_the_gpu():
+    # validate_init (render_config.rs:163-185) runs before any device call
+    from renderbaby_amd import Change, RenderConfig, scenes
+    lib = _lib.load()
+    s = scenes.sky_only()
+    rc = RenderConfig.from_scene(s)
+    rc.spheres = Change.update(s.spheres)
+    cfg, keep = rc.to_c()
+    assert not lib.rb_create(C.byref(cfg))
+    assert b"Invalid Spheres" in lib.rb_last_error(None)
+    assert not lib.rb_create(None)

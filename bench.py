@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- the contract benchmark (one JSON line on rank 0).
+
+Workload (BASELINE.json configs[1], "C2"): the seeded procedural Cornell box
+(12 triangles incl. the emissive ceiling quad, 8 spheres, 0 point lights),
+1920x1080, 1024 spp, max_depth 8.  A *step* is one full render of that frame:
+every pixel accumulates all 1024 samples in one launch of the hot kernel, with
+the scene already resident in HBM.  metric = Msamples/s where a sample is one
+ray segment (one executed iteration of the bounce loop, shader.wgsl:534),
+counted on the device and equal to the oracle's count.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's rows
+are sharded in interleaved stripes, every rank renders all samples of its rows,
+and one RCCL gather moves the RGBA8 rows to rank 0 inside the timed region
+("scaling": "strong" -- the total work is the same frame for every N).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline config)")
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--stripe-rows", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.achieved = null)")
+    return ap.parse_args()
+
+
+def make_scene(name, spp):
+    from renderbaby_amd import scenes
+    if name == "c1":
+        s = scenes.cornell_c1()
+        desc = "C1 Cornell box (12 tris, 8 spheres, 1 area light), 512x512, 64 spp, 4 bounces"
+    elif name == "c2":
+        s = scenes.cornell_c2()
+        desc = "C2 Cornell box (12 tris, 8 spheres, 1 area light), 1920x1080, 1024 spp, 8 bounces"
+    else:
+        s = scenes.mesh_c3()
+        desc = "C3 procedural 50176-tri mesh + light quad, BVH leaf<=128, 1920x1080, 256 spp, 5 bounces"
+    if spp:
+        s = s.with_params(spp=spp)
+        desc += f" [spp overridden to {spp}]"
+    return s, desc
+
+
+def cpu_baseline(scene, budget_s):
+    """The oracle (kind "port": the reference has no CPU path) on this host's cores,
+    on a bounded sample of the same workload: the full frame at n spp, n chosen to
+    fill about `budget_s` seconds."""
+    from tests import _oracle
+    cores = _oracle.lib().rbo_max_threads()
+    h = scene.height
+    probe_rows = max(8, min(h, 64))
+    r0 = (h - probe_rows) // 2
+    t = time.perf_counter()
+    _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + probe_rows))
+    dt = max(time.perf_counter() - t, 1e-6)
+    per_spp_full = dt * h / probe_rows
+    n = int(max(1, min(scene.total_samples, budget_s / per_spp_full)))
+    t = time.perf_counter()
+    _, _, _, st = _oracle.render(scene, 0, n)
+    dt = time.perf_counter() - t
+    return {"value": st["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"full {scene.width}x{scene.height} frame, {n} of {scene.total_samples} spp, "
+                      f"{st['segments']} segments in {dt:.2f} s (oracle/rb_oracle.c, OpenMP)"}
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic_*.json), or None."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        if d.get("workload") == workload:
+            best = d
+    return best
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        # convenience: spawn the one-rank-per-GPU launch as a child process
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the render path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    from renderbaby_amd import abi, engine
+    from renderbaby_amd.dist import ShardedRenderer
+
+    scene, desc = make_scene(a.workload, a.spp)
+    spp = scene.total_samples
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- instrumented pass (untimed): work counters for the algorithmic-bytes figure
+    stats = None
+    if not a.no_stats:
+        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True)
+        r.engine.reset_stats()
+        r.render_local()
+        stats = r.engine.stats()
+        r.close()
+
+    r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel)
+    for _ in range(a.warmup):
+        r.step()
+    r.engine.reset_stats()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r.step()
+        kernel_ms.append(r.engine.last_dispatch_ms())  # HIP events on the engine's stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = r.engine.stats()
+    seg_per_step = st["segments"] // max(a.steps, 1)
+    paths_per_step = st["paths"] // max(a.steps, 1)
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    cnt = torch.tensor([float(seg_per_step), float(paths_per_step)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    seg_total, paths_total = float(cnt[0].item()), float(cnt[1].item())
+
+    if rank == 0:
+        value = seg_total * a.steps / elapsed / 1e6
+        k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
+        if stats is not None and k_ms > 0:
+            owned, padded = r.owned, r.padded
+            algo = abi.algorithmic_bytes(stats, owned * scene.width, resumed=False)
+            roof["achieved"] = algo / (k_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS
+            roof["algorithmic_bytes_per_launch"] = algo
+            roof["bytes_per_segment"] = algo / max(stats["segments"], 1)
+            roof["kernel_ms"] = k_ms
+            roof["kernel"] = "k_queue<false>" if a.kernel in (0, 2) else "k_pixel<false>"
+        tr = load_traffic(a.workload)
+        if tr is not None:
+            roof["traffic"] = tr.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = tr.get("source")
+        cpu = None
+        if a.cpu_seconds > 0:
+            cpu = cpu_baseline(scene, a.cpu_seconds)
+        out = {
+            "metric": "Msamples/s (ray-segments/s)", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "width": scene.width, "height": scene.height, "spp": spp,
+                       "max_depth": int(scene.uniforms["max_depth"][0]), "segments_per_step": int(seg_total),
+                       "paths_per_step": int(paths_total), "Mpaths_per_s": paths_total * a.steps / elapsed / 1e6,
+                       "parallelism": f"row-stripes x{world}" if world > 1 else "single GPU",
+                       "stripe_rows": a.stripe_rows, "device": engine.device_name(local_rank)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["config"]["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -319,6 +319,17 @@ int rb_local_rows(const rb_engine* e, uint32_t* rows, uint32_t* padded_rows);
 /* Global row index of local row `local_row`. */
 int rb_global_row(const rb_engine* e, uint32_t local_row, uint32_t* global_row);
 
+/* Row-stripe sharding geometry as pure functions (no engine, no device): stripe s
+ * (rows [s*stripe_rows, (s+1)*stripe_rows)) belongs to rank s % shard_count; a
+ * rank stores its stripes back to back.  owned_rows = image rows the rank
+ * renders; padded_rows = rows of its local buffer, equal on every rank so that
+ * one equal-size gather moves the frame. */
+int rb_shard_layout(uint32_t height, uint32_t shard_rank, uint32_t shard_count, uint32_t stripe_rows,
+                    uint32_t* owned_rows, uint32_t* padded_rows);
+/* Global image row of a rank's local row (may be >= height in the padding). */
+uint32_t rb_shard_global_row(uint32_t shard_rank, uint32_t shard_count, uint32_t stripe_rows,
+                             uint32_t local_row);
+
 int rb_get_stats(rb_engine* e, rb_stats* out);
 int rb_reset_stats(rb_engine* e);
 /* Duration of the most recent rb_dispatch launch group, HIP events on the

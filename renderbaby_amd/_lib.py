@@ -56,6 +56,8 @@ def load():
         "rb_device_rgba": (i32, [vp, P(vp), P(sz)]),
         "rb_local_rows": (i32, [vp, P(u32), P(u32)]),
         "rb_global_row": (i32, [vp, u32, P(u32)]),
+        "rb_shard_layout": (i32, [u32, u32, u32, u32, P(u32), P(u32)]),
+        "rb_shard_global_row": (u32, [u32, u32, u32, u32]),
         "rb_get_stats": (i32, [vp, P(abi.Stats)]),
         "rb_reset_stats": (i32, [vp]),
         "rb_last_dispatch_ms": (i32, [vp, P(C.c_float)]),
@@ -75,5 +77,5 @@ def load():
 EXPORTS = ["rb_create", "rb_create_ex", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_last_error",
            "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
-           "rb_device_rgba", "rb_local_rows", "rb_global_row", "rb_get_stats", "rb_reset_stats",
+           "rb_device_rgba", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",
            "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_math", "rb_version", "rb_device_name"]

@@ -724,6 +724,30 @@ int rb_global_row(const rb_engine* e, uint32_t local_row, uint32_t* global_row) 
     return RB_OK;
 }
 
+int rb_shard_layout(uint32_t height, uint32_t shard_rank, uint32_t shard_count, uint32_t stripe_rows,
+                    uint32_t* owned_rows, uint32_t* padded_rows) {
+    const uint32_t sc = shard_count > 1 ? shard_count : 1;
+    const uint32_t sr = stripe_rows ? stripe_rows : rb::kDefaultStripeRows;
+    if (shard_rank >= sc) return RB_ERR_INVALID_OPTIONS;
+    uint32_t owned = height, padded = height;
+    if (sc > 1) {
+        const uint32_t stripes = (height + sr - 1) / sr;
+        padded = ((stripes + sc - 1) / sc) * sr;
+        owned = 0;
+        for (uint32_t s = shard_rank; s < stripes; s += sc) owned += std::min(sr, height - s * sr);
+    }
+    if (owned_rows) *owned_rows = owned;
+    if (padded_rows) *padded_rows = padded;
+    return RB_OK;
+}
+
+uint32_t rb_shard_global_row(uint32_t shard_rank, uint32_t shard_count, uint32_t stripe_rows, uint32_t local_row) {
+    const uint32_t sc = shard_count > 1 ? shard_count : 1;
+    const uint32_t sr = stripe_rows ? stripe_rows : rb::kDefaultStripeRows;
+    if (sc == 1) return local_row;
+    return ((local_row / sr) * sc + shard_rank) * sr + local_row % sr;
+}
+
 int rb_get_stats(rb_engine* e, rb_stats* out) {
     if (!e || !out) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);

@@ -215,13 +215,14 @@ typedef struct rb_options {
     uint32_t passes_per_launch; /* samples per pixel folded into one kernel launch; 0 = default */
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
-    uint32_t _reserved[5];
+    uint32_t _reserved[5];      /* [0] persistent blocks per CU (0 = default), [1] colour-buffer budget in MiB (0 = 4096) */
 } rb_options;
 
 enum {
     RB_KERNEL_DEFAULT = 0,
     RB_KERNEL_PIXEL = 1,  /* one thread per pixel, nested sample/depth loops */
-    RB_KERNEL_QUEUE = 2   /* persistent wavefronts, pixel queue + path regeneration */
+    RB_KERNEL_QUEUE = 2,  /* persistent wavefronts, pixel queue + path regeneration */
+    RB_KERNEL_STREAM = 3  /* persistent wavefronts over (pixel, sample) items + ordered accumulate pass */
 };
 
 enum {

@@ -59,7 +59,7 @@ ERR = {
     15: "NullArgument", 16: "Device", 17: "NotInitialized", 18: "InvalidOptions"}
 RB_ERR_NO_MORE_FRAMES = 12
 
-KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_QUEUE = 0, 1, 2
+KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_QUEUE, KERNEL_STREAM = 0, 1, 2, 3
 FLAG_STATS = 1
 
 

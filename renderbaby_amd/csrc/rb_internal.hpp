@@ -63,7 +63,8 @@ struct KParams {
     float* accum;                  // local_rows_padded * width * 4
     uint32_t* out_rgba;            // local_rows_padded * width, x mirrored
     unsigned long long* counters;  // C_COUNT
-    uint32_t* queue;               // work-queue head (RB_KERNEL_QUEUE)
+    uint32_t* queue;               // work-queue head (RB_KERNEL_QUEUE / RB_KERNEL_STREAM)
+    float* colors;                 // RB_KERNEL_STREAM: per-path radiance as float4, [tile][sample][64 pixels]
     uint32_t n_lights;             // arrayLength(&point_lights): >= 1 unless deleted
     uint32_t n_meshes;
     uint32_t index_len;            // arrayLength(&bvh_indices)
@@ -71,6 +72,9 @@ struct KParams {
     uint32_t n_tex;
     uint32_t first_pass, n_passes, samples_per_pass;
     uint32_t shard_rank, shard_count, stripe_rows, local_rows;  // local_rows: rows owned (unpadded)
+    uint32_t stack_depth;          // LDS traversal-stack entries per lane (0 for single-node trees)
+    uint32_t blocks_per_cu;        // persistent grid density (0 = default)
+    uint32_t queue_batch;          // items a wave reserves per global atomic (RB_KERNEL_STREAM)
 };
 
 struct LaunchInfo {

@@ -21,6 +21,24 @@
 
 #define DEV __device__ __forceinline__
 
+// Scene data is immutable for the duration of a launch.  Reading it through the
+// constant address space lets the compiler use scalar loads (s_load_*: one
+// fetch per wavefront, operands land in SGPRs) whenever the address is
+// wave-uniform -- spheres, lights, a single-leaf BVH -- and ordinary vector loads
+// otherwise.  Without this every lane issues its own VMEM load of the same
+// address, because the kernels also store (accumulation, traversal stack).
+#define RB_CONST __attribute__((address_space(4)))
+template <class T>
+DEV const RB_CONST T* cptr(const T* p) {
+    return (const RB_CONST T*)p;
+}
+// native vector types: HIP's float4/uint4 classes cannot be copy-constructed from address space 4
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef const RB_CONST v4f* cf4p;
+typedef const RB_CONST v4u* cu4p;
+typedef v4f nt_f4;  // nontemporal builtins want a native vector
+
 namespace rb {
 namespace {
 
@@ -104,13 +122,18 @@ DEV f3 sample_texture(const KParams& p, int32_t index, float uvx, float uvy) {
         return mk(1.0f, 1.0f, 1.0f);
     }
     if ((uint32_t)index >= p.n_tex) return mk(0.0f, 0.0f, 0.0f);
-    const rb_texture_info info = p.tex_info[index];
+    const v4u iw = ((cu4p)p.tex_info)[index];
+    rb_texture_info info;
+    info.offset = iw.x;
+    info.width = iw.y;
+    info.height = iw.z;
     float u = uvx - floorf(uvx);
     float v = uvy - floorf(uvy);
     uint32_t x = min(f2u(u * (float)info.width), info.width - 1u);
     uint32_t y = min(f2u((1.0f - v) * (float)info.height), info.height - 1u);
-    uint32_t pixel = p.tex_data[info.offset + y * info.width + x];
-    return mk(p.srgb_lut[pixel & 255u], p.srgb_lut[(pixel >> 8) & 255u], p.srgb_lut[(pixel >> 16) & 255u]);
+    const uint32_t pixel = cptr(p.tex_data)[info.offset + y * info.width + x];
+    const RB_CONST float* lut = cptr(p.srgb_lut);
+    return mk(lut[pixel & 255u], lut[(pixel >> 8) & 255u], lut[(pixel >> 16) & 255u]);
 }
 
 // ---------------------------------------------------------- intersection --
@@ -217,6 +240,18 @@ struct TriHit {
 // winner and is produced afterwards (tri_shade).  `stack` is this lane's column
 // of an LDS array [kStackDepth][blockDim]; the host has verified that the tree
 // fits (rb_bvh.cpp).
+DEV void test_slot(const v4f a, const v4f b, const v4f c, uint32_t slot, f3 o, f3 d, TriHit& h) {
+    float u, v;
+    const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+    if (t > 0.001f && t < h.t) {
+        h.hit = true;
+        h.t = t;
+        h.u = u;
+        h.v = v;
+        h.slot = slot;
+    }
+}
+
 template <bool STATS>
 DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     TriHit h;
@@ -228,6 +263,32 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
     const uint32_t node_count = p.u.bvh_node_count;
     if (node_count == 0u) return h;
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const cf4p nodes = (cf4p)p.nodes;
+    const cf4p ptris = (cf4p)p.ptris;
+
+    if (node_count == 1u) {
+        // Single-node tree (the Cornell box): no stack; the node and its triangles are
+        // wave-uniform, so they are fetched with scalar loads and every lane that is
+        // inside the box walks the same primitive list.  Same tests, same order.
+        const v4f n0 = nodes[0], n1 = nodes[1];
+        const v4u n2 = ((cu4p)p.nodes)[2];
+        if constexpr (STATS) tl.nodes++;
+        const uint32_t first = n2.z, count = n2.w;
+        if (count > 0u && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t slot = first + i;
+                if (slot >= p.index_len) continue;
+                const v4f a = ptris[slot * 3u], b = ptris[slot * 3u + 1u], c = ptris[slot * 3u + 2u];
+                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+                if constexpr (STATS) tl.tris++;
+                const float before = h.t;
+                test_slot(a, b, c, slot, o, d, h);
+                if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
+            }
+        }
+        return h;
+    }
+
     int sp = 0;
     stack[0] = 0u;
     sp = 1;
@@ -235,9 +296,8 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
         sp--;
         const uint32_t node_idx = stack[sp * stride];
         if (node_idx >= node_count) continue;
-        const float4* np = reinterpret_cast<const float4*>(p.nodes + node_idx);
-        const float4 n0 = np[0], n1 = np[1];
-        const uint4 n2 = reinterpret_cast<const uint4*>(np)[2];
+        const v4f n0 = nodes[node_idx * 3u], n1 = nodes[node_idx * 3u + 1u];
+        const v4u n2 = ((cu4p)p.nodes)[node_idx * 3u + 2u];
         if constexpr (STATS) tl.nodes++;
         if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
         const uint32_t left = n2.x, right = n2.y, first = n2.z, count = n2.w;
@@ -245,20 +305,12 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
             for (uint32_t i = 0; i < count; i++) {
                 const uint32_t slot = first + i;
                 if (slot >= p.index_len) continue;
-                const float4* tp = reinterpret_cast<const float4*>(p.ptris + slot);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const v4f a = ptris[slot * 3u], b = ptris[slot * 3u + 1u], c = ptris[slot * 3u + 2u];
                 if (__float_as_uint(c.w) == 0u) continue;  // guard :336
                 if constexpr (STATS) tl.tris++;
-                float u, v;
-                const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
-                if (t > 0.001f && t < h.t) {
-                    h.hit = true;
-                    h.t = t;
-                    h.u = u;
-                    h.v = v;
-                    h.slot = slot;
-                    if constexpr (STATS) tl.mesh_hits++;
-                }
+                const float before = h.t;
+                test_slot(a, b, c, slot, o, d, h);
+                if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
             }
         } else {
             if (left < node_count) {
@@ -274,15 +326,16 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
     return h;
 }
 
-DEV float uv_at(const KParams& p, uint32_t i) { return (i < p.n_uvs) ? p.uvs[i] : 0.0f; }
+DEV float uv_at(const KParams& p, uint32_t i) { return (i < p.n_uvs) ? cptr(p.uvs)[i] : 0.0f; }
 
 // shader.wgsl:353-361
 DEV void tri_uv(const KParams& p, const TriHit& h, float& uvx, float& uvy) {
-    const PrepTriShade s = p.pshade[h.slot];
+    const v4u s0 = ((cu4p)p.pshade)[h.slot * 2u], s1 = ((cu4p)p.pshade)[h.slot * 2u + 1u];
+    const uint32_t i0 = s0.w, i1 = s1.x, i2 = s1.y;  // v0_index, v1_index, v2_index
     const float w = 1.0f - h.u - h.v;
-    const float uv0x = uv_at(p, s.v0_index * 2u), uv0y = uv_at(p, s.v0_index * 2u + 1u);
-    const float uv1x = uv_at(p, s.v1_index * 2u), uv1y = uv_at(p, s.v1_index * 2u + 1u);
-    const float uv2x = uv_at(p, s.v2_index * 2u), uv2y = uv_at(p, s.v2_index * 2u + 1u);
+    const float uv0x = uv_at(p, i0 * 2u), uv0y = uv_at(p, i0 * 2u + 1u);
+    const float uv1x = uv_at(p, i1 * 2u), uv1y = uv_at(p, i1 * 2u + 1u);
+    const float uv2x = uv_at(p, i2 * 2u), uv2y = uv_at(p, i2 * 2u + 1u);
     uvx = (w * uv0x + h.u * uv1x) + h.v * uv2x;
     uvy = (w * uv0y + h.u * uv1y) + h.v * uv2y;
 }
@@ -294,15 +347,20 @@ struct Mat {
     int32_t tex;
 };
 DEV Mat load_mat(const rb_material* m) {
-    const float4* q = reinterpret_cast<const float4*>(m);
-    const float4 d = q[1], s = q[2], e = q[3];
+    const cf4p q = (cf4p)m;
+    const v4f d = q[1], s = q[2], e = q[3];
+    const v4u t = ((cu4p)m)[4];  // opacity, illum, texture_index, pad
     Mat r;
     r.diffuse = mk(d.x, d.y, d.z);
     r.specular = mk(s.x, s.y, s.z);
     r.shininess = s.w;
     r.emissive = mk(e.x, e.y, e.z);
-    r.tex = m->texture_index;
+    r.tex = (int32_t)t.z;
     return r;
+}
+DEV int32_t load_tex_index(const rb_material* m) {
+    const v4u t = ((cu4p)m)[4];
+    return (int32_t)t.z;
 }
 
 enum Kind : uint32_t { K_NONE = 0, K_GROUND = 1, K_TRI = 2, K_SPHERE = 3, K_LIGHT = 4 };
@@ -361,8 +419,9 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
     const float a = dot(d, d);
     uint32_t sphere_idx = 0xFFFFFFFFu;
     const uint32_t ns = p.u.spheres_count;
+    const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
     for (uint32_t k = 0; k < ns; k++) {
-        const float4 cr = *reinterpret_cast<const float4*>(p.spheres + k);
+        const v4f cr = sph4[k * 6u];
         if constexpr (STATS) tl.spheres++;
         const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
         if (t > 0.001f && t < closest_t) {
@@ -374,8 +433,9 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
 
     // Point lights :590-601
     uint32_t light_idx = 0xFFFFFFFFu;
+    const cf4p lgt4 = (cf4p)p.lights;
     for (uint32_t k = 0; k < p.n_lights; k++) {
-        const float4 cr = *reinterpret_cast<const float4*>(p.lights + k);
+        const v4f cr = lgt4[k * 6u];
         if constexpr (STATS) tl.lights++;
         const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
         if (t > 0.001f && t < closest_t) {
@@ -403,40 +463,46 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
     if (tri_won_a) {
         // the BVH hit replaced closest_hit, including uv and use_texture, even if a
         // sphere or light wins later (those never reset uv; lights never reset use_texture)
-        const PrepTri* pr = p.ptris + th.slot;
+        const cu4p pr = (cu4p)(p.ptris + th.slot);  // [0].w = tri_id, [1].w = mesh_index
         if (p.u.color_hash_enabled != 0u) {
             use_tex = false;
-            if (kind == K_TRI) m.diffuse = hash_to_color(pr->tri_id + 1u);
+            if (kind == K_TRI) {
+                const v4u p0 = pr[0];
+                m.diffuse = hash_to_color(p0.w + 1u);
+            }
         } else {
-            const rb_material* mm = &p.meshes[pr->mesh_index].material;
+            const v4u p1 = pr[1];
+            const rb_material* mm = &p.meshes[p1.w].material;
             if (kind == K_TRI) {
                 m = load_mat(mm);
                 use_tex = m.tex >= 0;
             } else {
-                use_tex = mm->texture_index >= 0;
+                use_tex = load_tex_index(mm) >= 0;
             }
         }
     }
     if (kind == K_GROUND) {
         m.diffuse = mk(0.5f, 0.5f, 0.5f);
     } else if (kind == K_TRI) {
-        const PrepTriShade s = p.pshade[th.slot];
-        normal = mk(s.n[0], s.n[1], s.n[2]);
+        const v4f s = ((cf4p)p.pshade)[th.slot * 2u];
+        normal = mk(s.x, s.y, s.z);
     } else {
         if (sphere_idx != 0xFFFFFFFFu) {
             const rb_sphere* s = p.spheres + sphere_idx;
             if (kind == K_SPHERE) {
                 m = load_mat(&s->material);
                 use_tex = m.tex >= 0;
-                normal = normalize(pos - ld3(s->center));
+                const v4f cr = ((cf4p)s)[0];
+                normal = normalize(pos - mk(cr.x, cr.y, cr.z));
             } else {
-                use_tex = s->material.texture_index >= 0;
+                use_tex = load_tex_index(&s->material) >= 0;
             }
         }
         if (kind == K_LIGHT) {
             const rb_point_light* l = p.lights + light_idx;
             m = load_mat(&l->material);
-            normal = normalize(pos - ld3(l->center));
+            const v4f cr = ((cf4p)l)[0];
+            normal = normalize(pos - mk(cr.x, cr.y, cr.z));
         }
     }
 
@@ -528,7 +594,7 @@ constexpr uint32_t kPixelBlock = 256;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
-    __shared__ uint32_t s_stack[kStackDepth * kPixelBlock];
+    extern __shared__ uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t tiles_x = (p.u.width + 15u) / 16u;
@@ -578,7 +644,7 @@ constexpr uint32_t kQueueBlock = 256;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
-    __shared__ uint32_t s_stack[kStackDepth * kQueueBlock];
+    extern __shared__ uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t width = p.u.width;
@@ -658,6 +724,143 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
     flush_tally<STATS>(tl, p.counters);
 }
 
+// ============================================== kernels: TRACE + ACCUMULATE ==
+// Two-phase form of the same computation.  Phase 1 (k_trace): persistent
+// wavefronts pull single (pixel, sample) items from a global queue -- a ballot of
+// the idle lanes, one atomic by the first idle lane for popcount(idle) items, a
+// prefix count to hand them out -- trace the path and store its radiance (16 B)
+// into an HBM buffer laid out [tile][sample][64 pixels].  A lane that finishes a
+// path regenerates at once, so all 64 lanes stay on the intersection code and
+// the launch tail is one path, not one pixel's worth of samples.  Nothing in
+// phase 1 depends on order.  Phase 2 (k_accumulate): one lane per pixel adds the
+// samples to the accumulation IN SAMPLE ORDER (f32 addition is not associative:
+// this is what keeps the frame bit-identical to the reference order,
+// shader.wgsl:712-717), then tone-maps and packs (:720-722).  Phase 2 is a
+// coalesced 1 KiB-per-wave stream and is HBM-bound; phase 1 is ALU-bound.
+constexpr uint32_t kTraceBlock = 256;
+
+template <bool STATS>
+__global__ void __launch_bounds__(kTraceBlock) k_trace(const KParams p) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const uint32_t total_items = tiles_x * tiles_y * S * 64u;  // host keeps this < 2^31
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    const Cam cam = make_cam(p);
+    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
+    Tally<STATS> tl;
+
+    bool active = false, exhausted = false;
+    uint32_t item = 0;
+    uint32_t loc_next = 0, loc_end = 0;  // this wave's reserved item range (wave-uniform)
+    const uint32_t batch = p.queue_batch;
+    Path pt;
+    pt.depth = 0;
+
+    for (;;) {
+        // ---- hand items to idle lanes.  The global queue is touched once per `batch`
+        // items (one word sustains only ~90 M atomics/s chip-wide); inside a batch the
+        // wave allocates with ballot + prefix count, no memory traffic.
+        unsigned long long idle = __ballot(!active);
+        for (int round = 0; round < 2 && idle != 0ull; round++) {
+            if (loc_next == loc_end) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(p.queue, batch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= total_items) {
+                    exhausted = true;
+                    break;
+                }
+                loc_next = b;
+                loc_end = (total_items - b < batch) ? total_items : b + batch;
+            }
+            const uint32_t avail = loc_end - loc_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = !active && rank < avail;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t taken = n_idle < avail ? n_idle : avail;
+            if (take) {
+                const uint32_t it = loc_next + rank;
+                const uint32_t in = it & 63u, ts = it >> 6;
+                const uint32_t tile = ts / S, smp = ts - tile * S;
+                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
+                bool ok = (x < width) && (ly < p.local_rows);
+                uint32_t y = 0;
+                if (ok) {
+                    y = global_row(p, ly);
+                    ok = y < p.u.height;
+                }
+                if (ok) {
+                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                    item = it;
+                    if (p.u.max_depth > 0u) {
+                        active = true;
+                    } else {
+                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        tl.paths++;
+                    }
+                }
+            }
+            loc_next += taken;
+            idle = __ballot(!active) & ~0ull;
+            if (taken == n_idle) break;  // everyone who asked was served (or got a padding item)
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted && loc_next == loc_end) break;
+            continue;
+        }
+        if (active) {
+            const bool alive = segment<STATS>(p, pt, &s_stack[tid], kTraceBlock, tl);
+            if (!alive) {
+                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                tl.paths++;
+                active = false;
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
+// Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,
+// lane = pixel; each sample row is a contiguous 1 KiB read.
+__global__ void __launch_bounds__(256) k_accumulate(const KParams p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    if (tile >= tiles_x * tiles_y) return;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), ly = ty * 8u + (lane >> 3);
+    if (x >= width || ly >= p.local_rows) return;
+    if (global_row(p, ly) >= p.u.height) return;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * width + x];
+    f3 acc = mk(a4.x, a4.y, a4.z);
+    uint32_t total = f2u(a4.w);
+    const nt_f4* __restrict__ c = reinterpret_cast<const nt_f4*>(p.colors) + ((size_t)tile * S) * 64u + lane;
+    uint32_t s = 0;
+    for (; s + 8u <= S; s += 8u) {
+        nt_f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(&c[(size_t)(s + k) * 64u]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = acc + mk(v[k].x, v[k].y, v[k].z);
+    }
+    for (; s < S; s++) {
+        const nt_f4 v = __builtin_nontemporal_load(&c[(size_t)s * 64u]);
+        acc = acc + mk(v.x, v.y, v.z);
+    }
+    total += S;
+    store_pixel(p, x, ly, acc, total);
+}
+
 // ============================================================ prep kernel ==
 // Gathers triangles into bvh_indices order and hoists the per-triangle
 // invariants (edge1, edge2, geometric normal) of shader.wgsl:249-250,351.
@@ -718,37 +921,64 @@ int device_cu_count(int device) {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
+static uint32_t persistent_blocks(uint64_t items, uint32_t block, uint32_t blocks_per_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t blocks = (uint32_t)device_cu_count(dev) * blocks_per_cu;
+    const uint64_t needed = (items + block - 1) / block;
+    if (needed < blocks) blocks = (uint32_t)needed;
+    return blocks;
+}
+
 int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LaunchInfo li{};
+    const size_t lds = sizeof(uint32_t) * p.stack_depth * 256u;
+    li.lds_bytes = lds;
     if (kernel == RB_KERNEL_PIXEL) {
         const uint32_t tiles_x = (p.u.width + 15u) / 16u, tiles_y = (p.local_rows + 15u) / 16u;
         li.grid = tiles_x * tiles_y;
         li.block = kPixelBlock;
-        li.lds_bytes = sizeof(uint32_t) * kStackDepth * kPixelBlock;
         if (li.grid == 0) return 0;
         if (stats)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(li.grid), dim3(li.block), 0, stream, p);
+            hipLaunchKernelGGL(k_pixel<true>, dim3(li.grid), dim3(li.block), lds, stream, p);
         else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(li.grid), dim3(li.block), 0, stream, p);
-    } else {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const uint32_t cus = (uint32_t)device_cu_count(dev);
+            hipLaunchKernelGGL(k_pixel<false>, dim3(li.grid), dim3(li.block), lds, stream, p);
+    } else if (kernel == RB_KERNEL_QUEUE) {
         const uint64_t items = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u) * 64u;
-        uint32_t blocks = cus * 4u;  // 16 waves per CU
-        const uint64_t needed = (items + kQueueBlock - 1) / kQueueBlock;
-        if (needed < blocks) blocks = (uint32_t)needed;
-        li.grid = blocks;
+        li.grid = persistent_blocks(items, kQueueBlock, 4u);  // 16 waves per CU
         li.block = kQueueBlock;
-        li.lds_bytes = sizeof(uint32_t) * kStackDepth * kQueueBlock;
         if (li.grid == 0) return 0;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
         if (stats)
-            hipLaunchKernelGGL(k_queue<true>, dim3(li.grid), dim3(li.block), 0, stream, p);
+            hipLaunchKernelGGL(k_queue<true>, dim3(li.grid), dim3(li.block), lds, stream, p);
         else
-            hipLaunchKernelGGL(k_queue<false>, dim3(li.grid), dim3(li.block), 0, stream, p);
+            hipLaunchKernelGGL(k_queue<false>, dim3(li.grid), dim3(li.block), lds, stream, p);
+    } else {
+        const uint64_t tiles = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u);
+        const uint64_t items = tiles * 64u * p.n_passes * p.samples_per_pass;
+        li.grid = persistent_blocks(items, kTraceBlock, p.blocks_per_cu ? p.blocks_per_cu : 4u);
+        li.block = kTraceBlock;
+        if (li.grid == 0) return 0;
+        // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64
+        KParams q = p;
+        const uint64_t waves = (uint64_t)li.grid * (kTraceBlock / 64u);
+        uint64_t batch = items / (waves * 64u);
+        batch = (batch / 64u) * 64u;
+        if (batch < 64u) batch = 64u;
+        if (batch > 4096u) batch = 4096u;
+        if (p.queue_batch) batch = p.queue_batch;
+        q.queue_batch = (uint32_t)batch;
+        hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return (int)e;
+        if (stats)
+            hipLaunchKernelGGL(k_trace<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        else
+            hipLaunchKernelGGL(k_trace<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((tiles + 3u) / 4u)), dim3(256), 0, stream, p);
     }
     if (info) *info = li;
     return (int)hipGetLastError();

@@ -86,6 +86,8 @@ struct rb_engine {
     DevBuf<uint32_t> out_rgba;
     DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> queue;
+    DevBuf<float> colors;            // RB_KERNEL_STREAM: float4 per (pixel, sample) of one launch chunk
+    uint32_t bvh_stack = 0;          // traversal-stack entries the current tree needs
 
     std::vector<rb_bvh_node> host_nodes;  // kept for validation when nodes/indices change separately
     uint32_t width = 0, height = 0, local_rows = 0, padded_rows = 0;
@@ -311,6 +313,7 @@ int validate_scene(rb_engine* e, const rb_config* cfg) {
     if (n_nodes > 0) {
         if (!rb::bvh_validate(e->host_nodes.data(), n_nodes, rb::kStackDepth, why, &depth))
             return fail(e, RB_ERR_INVALID_BVH, "%s", why.c_str());
+        e->bvh_stack = depth;
         for (uint32_t i = 0; i < n_nodes; ++i) {
             const rb_bvh_node& n = e->host_nodes[i];
             if (n.primitive_count > 0 &&
@@ -378,6 +381,11 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.shard_count = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
     p.stripe_rows = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     p.local_rows = e->local_rows;
+    p.colors = e->colors.ptr;
+    // a single-node tree is walked without a stack (rb_kernels.hip, intersect_bvh)
+    p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
+    p.blocks_per_cu = e->opt._reserved[0];
+    p.queue_batch = e->opt._reserved[2];
     return p;
 }
 
@@ -399,9 +407,22 @@ int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     int rc = ensure_prepared(e);
     if (rc) return rc;
     if (n_passes == 0 || e->width == 0 || e->local_rows == 0) return RB_OK;
-    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_QUEUE;
+    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
     const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
     uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
+    if (kernel == RB_KERNEL_STREAM) {
+        // One float4 per (pixel, sample) of a launch chunk.  Keep the item count below 2^31
+        // and, unless the caller fixed the chunk, the buffer within a budget (default 4 GiB:
+        // small against 288 GB of HBM, large enough that launch boundaries do not matter).
+        const uint64_t tiles = static_cast<uint64_t>((e->width + 7) / 8) * ((e->local_rows + 7) / 8);
+        const uint64_t per_pass = tiles * 64ull * e->prh.samples_per_pass;  // items per pass
+        const uint64_t budget_items = (e->opt._reserved[1] ? static_cast<uint64_t>(e->opt._reserved[1]) : 4096ull) * (1ull << 20) / 16ull;
+        uint64_t max_chunk = std::min<uint64_t>((1ull << 31) / std::max<uint64_t>(per_pass, 1) , 0xFFFFFFFFull);
+        if (!e->opt.passes_per_launch) max_chunk = std::min(max_chunk, std::max<uint64_t>(budget_items / std::max<uint64_t>(per_pass, 1), 1));
+        if (max_chunk == 0) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame too large for one launch");
+        chunk = static_cast<uint32_t>(std::min<uint64_t>(chunk, max_chunk));
+        HIP_TRY(e, e->colors.resize(per_pass * chunk * 4));
+    }
     HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
     uint32_t launches = 0;
     for (uint32_t done = 0; done < n_passes;) {
@@ -514,7 +535,7 @@ rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
         fail(nullptr, RB_ERR_INVALID_OPTIONS, "shard_rank %u >= shard_count %u", opt.shard_rank, opt.shard_count);
         return nullptr;
     }
-    if (opt.kernel > RB_KERNEL_QUEUE) { fail(nullptr, RB_ERR_INVALID_OPTIONS, "unknown kernel %u", opt.kernel); return nullptr; }
+    if (opt.kernel > RB_KERNEL_STREAM) { fail(nullptr, RB_ERR_INVALID_OPTIONS, "unknown kernel %u", opt.kernel); return nullptr; }
     int dev = opt.device;
     if (dev < 0) {
         if (hipGetDevice(&dev) != hipSuccess) { fail(nullptr, RB_ERR_DEVICE, "no HIP device available"); return nullptr; }

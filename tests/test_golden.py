@@ -27,7 +27,7 @@ def test_oracle_reproduces_golden(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 2], ids=["pixel", "queue"])
+@pytest.mark.parametrize("kernel", [1, 2, 3], ids=["pixel", "queue", "stream"])
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_hip_reproduces_golden(path, kernel):
     from renderbaby_amd import Engine, RenderConfig

@@ -12,7 +12,7 @@ from tests import _oracle
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [abi.KERNEL_PIXEL, abi.KERNEL_QUEUE]
+KERNELS = [abi.KERNEL_PIXEL, abi.KERNEL_QUEUE, abi.KERNEL_STREAM]
 
 
 def _hip(scene, kernel, stats=True, **kw):
@@ -92,3 +92,56 @@ def test_device_math_is_ieee():
         assert np.array_equal(out[5].view(np.uint32), exp.view(np.uint32)), "u32->f32"
         exp = ((a * b + b * b).astype(np.float32) + a * a).astype(np.float32)
         assert np.array_equal(out[7].view(np.uint32), exp.view(np.uint32)), "dot: contraction or reassociation"
+
+
+def test_stream_kernel_chunking_is_bit_identical():
+    # the (pixel, sample) stream is cut into launch chunks by passes_per_launch / the
+    # colour-buffer budget; any cut must give the same frame
+    s = scenes.feature_scene(40, 24, 7, 5)
+    o_acc, _, o_rgba, _ = _oracle.render(s)
+    for ppl in (0, 1, 3, 7):
+        frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=False, passes_per_launch=ppl)
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), ppl
+        assert np.array_equal(frame.pixels, o_rgba), ppl
+    frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=False, color_budget_mib=1)
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_progressive_iterator_matches_blocking_render(kernel):
+    # frame k of the iterator = running average of samples 0..k (lib.rs:169-228)
+    s = scenes.cornell(40, 24, 4, 4)
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc, kernel=kernel)
+    it = eng.frame_iterator(rc)
+    frames = []
+    while it.has_next():
+        frames.append(it.next().pixels.copy())
+    assert len(frames) == 4
+    with pytest.raises(Exception) as ei:
+        it.next()
+    assert "No more frames available" in str(ei.value)
+    for k in range(4):
+        _, _, o_rgba, _ = _oracle.render(s, 0, k + 1)
+        assert np.array_equal(frames[k], o_rgba), k
+    # a new iterator restarts at pass 0 with a cleared accumulation (lib.rs:91,181-192)
+    it2 = eng.frame_iterator(RenderConfig.from_scene(s, create=False))
+    assert np.array_equal(it2.next().pixels, frames[0])
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("world,stripe_rows", [(2, 16), (3, 4), (8, 1)])
+def test_sharded_engines_reassemble_the_single_gpu_frame(kernel, world, stripe_rows):
+    import torch
+    from renderbaby_amd import dist as rdist
+    s = scenes.cornell(48, 37, 3, 4)
+    rc = RenderConfig.from_scene(s)
+    full = Engine.new(rc, kernel=kernel).render(rc).pixels
+    parts = []
+    for r in range(world):
+        eng = Engine.new(rc, kernel=kernel, shard_rank=r, shard_count=world, stripe_rows=stripe_rows)
+        parts.append(torch.from_numpy(eng.render(rc).pixels.copy()))
+        eng.close()
+    frame = rdist.assemble(parts, s.height, stripe_rows).numpy()
+    assert np.array_equal(frame, full)

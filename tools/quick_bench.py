@@ -26,6 +26,6 @@ if __name__ == "__main__":
         s = scenes.cornell(1920, 1080, 64, 8)
     elif which == "c3s":
         s = scenes.mesh_scene(112, 112, 1920, 1080, 8, 5)
-    for k, name in ((abi.KERNEL_PIXEL, "pixel"), (abi.KERNEL_QUEUE, "queue")):
+    for k, name in ((abi.KERNEL_PIXEL, "pixel"), (abi.KERNEL_QUEUE, "queue"), (abi.KERNEL_STREAM, "stream")):
         ms, st = run(s, k)
         print(f"{which} {name}: {ms:.2f} ms  segments={st['segments']}  {st['segments']/ms/1e3:.1f} Mseg/s  paths/s={st['paths']/ms/1e3:.1f} M")

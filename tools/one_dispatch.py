@@ -1,0 +1,18 @@
+"""One clean dispatch of a workload for profiling: python tools/one_dispatch.py c2 64 [kernel] [reps]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderbaby_amd import Engine, RenderConfig, abi, scenes
+w = sys.argv[1] if len(sys.argv) > 1 else "c2"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+kern = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+if w == "c1": s = scenes.cornell(512, 512, spp, 4)
+elif w == "c2": s = scenes.cornell(1920, 1080, spp, 8)
+elif w == "c3": s = scenes.mesh_scene(112, 112, 1920, 1080, spp, 5)
+rc = RenderConfig.from_scene(s)
+eng = Engine.new(rc, kernel=kern); eng.update(rc)
+for _ in range(reps):
+    eng.reset_stats(); eng.clear(); eng.dispatch(0, spp); eng.sync()
+st = eng.stats()
+print(w, spp, "kernel", kern, "ms", eng.last_dispatch_ms(), "segments", st["segments"], "Mseg/s", st["segments"] / eng.last_dispatch_ms() / 1e3)
+eng.close()

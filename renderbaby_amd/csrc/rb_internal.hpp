@@ -29,20 +29,21 @@ enum Counter : uint32_t {
 // shader.wgsl:249-250,351 hoisted out of the per-ray loop.  edge1/edge2/normal
 // are computed on the device by the same f32 operations the shader performs per
 // test, so every ray sees bit-identical values.
-struct alignas(16) PrepTri {
+struct alignas(16) PrepTri {   // 64 B: one s_load_dwordx16 (uniform) or four 16-B vector loads
     float v0[3];
     uint32_t tri_id;    // index into bvh_triangles (for hash_to_color and the :336 guard)
-    float e1[3];
+    float e1[3];        // v1 - v0
     uint32_t mesh_index;
-    float e2[3];
+    float e2[3];        // v2 - v0
     uint32_t valid;     // 0 when a guard of shader.wgsl:331,336 would `continue`
+    float n[3];         // normalize(cross(e1, e2))  (shader.wgsl:351)
+    uint32_t _pad;
 };
-struct alignas(16) PrepTriShade {
-    float n[3];         // normalize(cross(e1, e2))
+struct alignas(16) PrepTriShade {   // 16 B: uv lookup indices (shader.wgsl:357-359)
     uint32_t v0_index;
     uint32_t v1_index;
     uint32_t v2_index;
-    uint32_t _pad[2];
+    uint32_t _pad;
 };
 
 // Everything a render launch needs.  Passed by value (kernarg segment => scalar loads).

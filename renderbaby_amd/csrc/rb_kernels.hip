@@ -21,6 +21,12 @@
 
 #define DEV __device__ __forceinline__
 
+// Cost-attribution builds (tools/ablate.sh): RB_ABLATE=n repeats one stage on perturbed-but-equal
+// inputs and folds the result into nothing observable, so (time[n] - time[0]) is that stage's cost.
+#ifndef RB_ABLATE
+#define RB_ABLATE 0
+#endif
+
 // Scene data is immutable for the duration of a launch.  Reading it through the
 // constant address space lets the compiler use scalar loads (s_load_*: one
 // fetch per wavefront, operands land in SGPRs) whenever the address is
@@ -153,25 +159,46 @@ DEV float isect_sphere(f3 o, f3 d, float a, f3 center, float radius) {
     return root;
 }
 
-// shader.wgsl:248-280 with edge1/edge2 supplied (v1 - v0, v2 - v0)
+// shader.wgsl:248-280 with edge1/edge2 supplied (v1 - v0, v2 - v0).  RB_TRI_BRANCHFREE=1
+// evaluates everything and folds the four early returns into one predicate (same
+// comparisons on the same values); measured slower on gfx950 (34.8 vs 33.5 ms on C2-short)
+// because the early-outs do skip whole-wave work, so the branchy form is the default.
+#ifndef RB_TRI_BRANCHFREE
+#define RB_TRI_BRANCHFREE 0
+#endif
 DEV float isect_triangle(f3 o, f3 d, f3 v0, f3 edge1, f3 edge2, float& uo, float& vo) {
-    f3 h = cross(d, edge2);
-    float a = dot(edge1, h);
+#if RB_TRI_BRANCHFREE
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = 1.0f / a;
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(edge2, q);
+    const bool miss = (fabsf(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | !(t > 0.0f);
+    uo = u;
+    vo = v;
+    return miss ? -1.0f : t;
+#else
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
     if (fabsf(a) < 1e-6f) return -1.0f;
-    float f = 1.0f / a;
-    f3 s = o - v0;
-    float u = f * dot(s, h);
+    const float f = 1.0f / a;
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
     if (u < 0.0f || u > 1.0f) return -1.0f;
-    f3 q = cross(s, edge1);
-    float v = f * dot(d, q);
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
     if (v < 0.0f || u + v > 1.0f) return -1.0f;
-    float t = f * dot(edge2, q);
+    const float t = f * dot(edge2, q);
     if (t > 0.0f) {
         uo = u;
         vo = v;
         return t;
     }
     return -1.0f;
+#endif
 }
 
 // shader.wgsl:664-671 with inv_dir = 1/dir hoisted per ray (pure function of dir)
@@ -264,26 +291,32 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
     if (node_count == 0u) return h;
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const cf4p nodes = (cf4p)p.nodes;
-    const cf4p ptris = (cf4p)p.ptris;
+    const cf4p ptris = (cf4p)p.ptris;  // 4 x float4 per triangle
 
     if (node_count == 1u) {
         // Single-node tree (the Cornell box): no stack; the node and its triangles are
         // wave-uniform, so they are fetched with scalar loads and every lane that is
-        // inside the box walks the same primitive list.  Same tests, same order.
+        // inside the box walks the same primitive list.  Same tests, same order.  The next
+        // triangle's record is requested before the current one is tested.
         const v4f n0 = nodes[0], n1 = nodes[1];
         const v4u n2 = ((cu4p)p.nodes)[2];
         if constexpr (STATS) tl.nodes++;
         const uint32_t first = n2.z, count = n2.w;
-        if (count > 0u && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t slot = first + i;
-                if (slot >= p.index_len) continue;
-                const v4f a = ptris[slot * 3u], b = ptris[slot * 3u + 1u], c = ptris[slot * 3u + 2u];
-                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
-                if constexpr (STATS) tl.tris++;
-                const float before = h.t;
-                test_slot(a, b, c, slot, o, d, h);
-                if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
+        const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
+        if (first < end && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
+            v4f a = ptris[first * 4u], b = ptris[first * 4u + 1u], c = ptris[first * 4u + 2u];
+            for (uint32_t slot = first; slot < end; slot++) {
+                const uint32_t nx = (slot + 1u < end) ? slot + 1u : slot;
+                const v4f na = ptris[nx * 4u], nb = ptris[nx * 4u + 1u], nc = ptris[nx * 4u + 2u];
+                if (__float_as_uint(c.w) != 0u) {  // guard :336
+                    if constexpr (STATS) tl.tris++;
+                    const float before = h.t;
+                    test_slot(a, b, c, slot, o, d, h);
+                    if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
+                }
+                a = na;
+                b = nb;
+                c = nc;
             }
         }
         return h;
@@ -305,7 +338,7 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
             for (uint32_t i = 0; i < count; i++) {
                 const uint32_t slot = first + i;
                 if (slot >= p.index_len) continue;
-                const v4f a = ptris[slot * 3u], b = ptris[slot * 3u + 1u], c = ptris[slot * 3u + 2u];
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
                 if (__float_as_uint(c.w) == 0u) continue;  // guard :336
                 if constexpr (STATS) tl.tris++;
                 const float before = h.t;
@@ -330,8 +363,8 @@ DEV float uv_at(const KParams& p, uint32_t i) { return (i < p.n_uvs) ? cptr(p.uv
 
 // shader.wgsl:353-361
 DEV void tri_uv(const KParams& p, const TriHit& h, float& uvx, float& uvy) {
-    const v4u s0 = ((cu4p)p.pshade)[h.slot * 2u], s1 = ((cu4p)p.pshade)[h.slot * 2u + 1u];
-    const uint32_t i0 = s0.w, i1 = s1.x, i2 = s1.y;  // v0_index, v1_index, v2_index
+    const v4u s0 = ((cu4p)p.pshade)[h.slot];
+    const uint32_t i0 = s0.x, i1 = s0.y, i2 = s0.z;  // v0_index, v1_index, v2_index
     const float w = 1.0f - h.u - h.v;
     const float uv0x = uv_at(p, i0 * 2u), uv0y = uv_at(p, i0 * 2u + 1u);
     const float uv1x = uv_at(p, i1 * 2u), uv1y = uv_at(p, i1 * 2u + 1u);
@@ -409,41 +442,113 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
 
     // BVH triangles :568-571
     const TriHit th = intersect_bvh<STATS>(p, o, d, stack, stride, tl);
+#if RB_ABLATE == 1
+    {
+        f3 o2 = o;
+        asm volatile("" : "+v"(o2.x));
+        Tally<STATS> t2;
+        const TriHit th2 = intersect_bvh<STATS>(p, o2, d, stack, stride, t2);
+        asm volatile("" ::"v"(th2.t), "v"(th2.slot));
+    }
+#endif
     const bool tri_won_a = th.hit && th.t < closest_t;  // closest_hit = bvh_hit
     if (tri_won_a) {
         closest_t = th.t;
         kind = K_TRI;
     }
 
-    // Spheres :574-586
+    // Spheres :574-586 and point lights :590-601.  Two passes with the reference's arithmetic:
+    // pass 1 evaluates the discriminant of every sphere with wave-uniform scalar loads and
+    // records the candidates (disc >= 0) in a per-lane bit mask; pass 2 runs the sqrt/divide
+    // tail only for a lane's own candidates, in ascending index order, so the strict `<`
+    // keeps the same winner.  Most lanes have no candidate, so the expensive tail is issued
+    // once or twice per segment instead of once per sphere.
     const float a = dot(d, d);
     uint32_t sphere_idx = 0xFFFFFFFFu;
     const uint32_t ns = p.u.spheres_count;
     const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
-    for (uint32_t k = 0; k < ns; k++) {
-        const v4f cr = sph4[k * 6u];
-        if constexpr (STATS) tl.spheres++;
-        const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-        if (t > 0.001f && t < closest_t) {
-            closest_t = t;
-            sphere_idx = k;
+    for (uint32_t base = 0; base < ns; base += 32u) {
+        const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
+        uint32_t cand = 0u;
+        for (uint32_t k = 0; k < n; k++) {
+            const v4f cr = sph4[(base + k) * 6u];
+            if constexpr (STATS) tl.spheres++;
+            const f3 oc = o - mk(cr.x, cr.y, cr.z);
+            const float half_b = dot(oc, d);
+            const float c = dot(oc, oc) - cr.w * cr.w;
+            const float disc = half_b * half_b - a * c;
+            cand |= (disc < 0.0f) ? 0u : (1u << k);
+        }
+        while (cand != 0u) {
+            const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+            cand &= cand - 1u;
+            const v4f cr = sph4[(base + k) * 6u];
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && t < closest_t) {
+                closest_t = t;
+                sphere_idx = base + k;
+            }
         }
     }
     if (sphere_idx != 0xFFFFFFFFu) kind = K_SPHERE;
 
-    // Point lights :590-601
     uint32_t light_idx = 0xFFFFFFFFu;
     const cf4p lgt4 = (cf4p)p.lights;
-    for (uint32_t k = 0; k < p.n_lights; k++) {
-        const v4f cr = lgt4[k * 6u];
-        if constexpr (STATS) tl.lights++;
-        const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-        if (t > 0.001f && t < closest_t) {
-            closest_t = t;
-            light_idx = k;
+    for (uint32_t base = 0; base < p.n_lights; base += 32u) {
+        const uint32_t n = (p.n_lights - base < 32u) ? p.n_lights - base : 32u;
+        uint32_t cand = 0u;
+        for (uint32_t k = 0; k < n; k++) {
+            const v4f cr = lgt4[(base + k) * 6u];
+            if constexpr (STATS) tl.lights++;
+            const f3 oc = o - mk(cr.x, cr.y, cr.z);
+            const float half_b = dot(oc, d);
+            const float c = dot(oc, oc) - cr.w * cr.w;
+            const float disc = half_b * half_b - a * c;
+            cand |= (disc < 0.0f) ? 0u : (1u << k);
+        }
+        while (cand != 0u) {
+            const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+            cand &= cand - 1u;
+            const v4f cr = lgt4[(base + k) * 6u];
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && t < closest_t) {
+                closest_t = t;
+                light_idx = base + k;
+            }
         }
     }
     if (light_idx != 0xFFFFFFFFu) kind = K_LIGHT;
+#if RB_ABLATE == 2
+    {
+        f3 o2 = o;
+        asm volatile("" : "+v"(o2.x));
+        float ct = 1e20f;
+        uint32_t si = 0;
+        for (uint32_t base = 0; base < ns; base += 32u) {
+            const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
+            uint32_t cand = 0u;
+            for (uint32_t k = 0; k < n; k++) {
+                const v4f cr = sph4[(base + k) * 6u];
+                const f3 oc = o2 - mk(cr.x, cr.y, cr.z);
+                const float half_b = dot(oc, d);
+                const float c = dot(oc, oc) - cr.w * cr.w;
+                const float disc = half_b * half_b - a * c;
+                cand |= (disc < 0.0f) ? 0u : (1u << k);
+            }
+            while (cand != 0u) {
+                const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+                cand &= cand - 1u;
+                const v4f cr = sph4[(base + k) * 6u];
+                const float t = isect_sphere(o2, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+                if (t > 0.001f && t < ct) {
+                    ct = t;
+                    si = base + k;
+                }
+            }
+        }
+        asm volatile("" ::"v"(ct), "v"(si));
+    }
+#endif
 
     // Sky :604-608
     if (kind == K_NONE) {
@@ -463,7 +568,7 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
     if (tri_won_a) {
         // the BVH hit replaced closest_hit, including uv and use_texture, even if a
         // sphere or light wins later (those never reset uv; lights never reset use_texture)
-        const cu4p pr = (cu4p)(p.ptris + th.slot);  // [0].w = tri_id, [1].w = mesh_index
+        const cu4p pr = (cu4p)p.ptris + th.slot * 4u;  // [0].w = tri_id, [1].w = mesh_index
         if (p.u.color_hash_enabled != 0u) {
             use_tex = false;
             if (kind == K_TRI) {
@@ -484,7 +589,7 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
     if (kind == K_GROUND) {
         m.diffuse = mk(0.5f, 0.5f, 0.5f);
     } else if (kind == K_TRI) {
-        const v4f s = ((cf4p)p.pshade)[th.slot * 2u];
+        const v4f s = ((cf4p)p.ptris)[th.slot * 4u + 3u];
         normal = mk(s.x, s.y, s.z);
     } else {
         if (sphere_idx != 0xFFFFFFFFu) {
@@ -512,6 +617,14 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
 
     pt.color = pt.color + pt.att * m.emissive;  // :626
 
+#if RB_ABLATE == 3
+    {
+        uint32_t s2 = pt.seed;
+        asm volatile("" : "+v"(s2));
+        const f3 r2 = random_unit_vector(s2);
+        asm volatile("" ::"v"(r2.x), "v"(r2.y), "v"(r2.z));
+    }
+#endif
     f3 scattered, albedo;
     if (is_metal) {
         const float fuzz = fminf(fmaxf(1.0f - (m.shininess / 1000.0f), 0.0f), 1.0f);
@@ -798,6 +911,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const KParams p) {
                 }
                 if (ok) {
                     start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+#if RB_ABLATE == 4
+                    {
+                        Path p2;
+                        uint32_t x2 = x;
+                        asm volatile("" : "+v"(x2));
+                        start_path(p, cam, x2, y, y * width + x2, sample_base + smp, p2);
+                        asm volatile("" ::"v"(p2.d.x), "v"(p2.d.y), "v"(p2.d.z), "v"(p2.seed));
+                    }
+#endif
                     item = it;
                     if (p.u.max_depth > 0u) {
                         active = true;
@@ -883,14 +1005,15 @@ __global__ void k_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, con
         t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
         t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
         t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+        t.n[0] = n.x; t.n[1] = n.y; t.n[2] = n.z;
         t.tri_id = id;
         t.mesh_index = g.mesh_index;
         t.valid = 1u;
-        s.n[0] = n.x; s.n[1] = n.y; s.n[2] = n.z;
+        t._pad = 0u;
         s.v0_index = g.v0_index;
         s.v1_index = g.v1_index;
         s.v2_index = g.v2_index;
-        s._pad[0] = s._pad[1] = 0u;
+        s._pad = 0u;
     }
     out[slot] = t;
     shade[slot] = s;
@@ -946,7 +1069,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
             hipLaunchKernelGGL(k_pixel<false>, dim3(li.grid), dim3(li.block), lds, stream, p);
     } else if (kernel == RB_KERNEL_QUEUE) {
         const uint64_t items = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u) * 64u;
-        li.grid = persistent_blocks(items, kQueueBlock, 4u);  // 16 waves per CU
+        li.grid = persistent_blocks(items, kQueueBlock, p.blocks_per_cu ? p.blocks_per_cu : 8u);  // residency is set by VGPRs
         li.block = kQueueBlock;
         if (li.grid == 0) return 0;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
@@ -958,7 +1081,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
     } else {
         const uint64_t tiles = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u);
         const uint64_t items = tiles * 64u * p.n_passes * p.samples_per_pass;
-        li.grid = persistent_blocks(items, kTraceBlock, p.blocks_per_cu ? p.blocks_per_cu : 4u);
+        li.grid = persistent_blocks(items, kTraceBlock, p.blocks_per_cu ? p.blocks_per_cu : 8u);
         li.block = kTraceBlock;
         if (li.grid == 0) return 0;
         // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64

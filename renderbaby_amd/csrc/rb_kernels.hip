@@ -417,7 +417,7 @@ DEV bool near_zero(f3 v) {                                                // :46
 // same way; per-hit data that only the final winner needs (position, normal,
 // material, uv) is produced once, after the search.
 template <bool STATS>
-DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, Tally<STATS>& tl) {
     const f3 o = pt.o, d = pt.d;
     tl.segments++;
 
@@ -440,17 +440,7 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
         }
     }
 
-    // BVH triangles :568-571
-    const TriHit th = intersect_bvh<STATS>(p, o, d, stack, stride, tl);
-#if RB_ABLATE == 1
-    {
-        f3 o2 = o;
-        asm volatile("" : "+v"(o2.x));
-        Tally<STATS> t2;
-        const TriHit th2 = intersect_bvh<STATS>(p, o2, d, stack, stride, t2);
-        asm volatile("" ::"v"(th2.t), "v"(th2.slot));
-    }
-#endif
+    // BVH triangles :568-571 (th: the traversal's winner, produced by the caller)
     const bool tri_won_a = th.hit && th.t < closest_t;  // closest_hit = bvh_hit
     if (tri_won_a) {
         closest_t = th.t;
@@ -646,6 +636,22 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
     pt.d = normalize(scattered);
     pt.depth++;
     return pt.depth < p.u.max_depth;
+}
+
+// One whole iteration of the bounce loop: traversal + everything else.
+template <bool STATS>
+DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    const TriHit th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, stride, tl);
+#if RB_ABLATE == 1
+    {
+        f3 o2 = pt.o;
+        asm volatile("" : "+v"(o2.x));
+        Tally<STATS> t2;
+        const TriHit th2 = intersect_bvh<STATS>(p, o2, pt.d, stack, stride, t2);
+        asm volatile("" ::"v"(th2.t), "v"(th2.slot));
+    }
+#endif
+    return segment_finish<STATS>(p, pt, th, tl);
 }
 
 // ----------------------------------------------------------------- camera --
@@ -949,6 +955,169 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const KParams p) {
     flush_tally<STATS>(tl, p.counters);
 }
 
+// k_trace for multi-node BVHs.  With 128-triangle leaves and no t-culling (the reference's
+// traversal, kept for exactness) a ray visits a handful of leaves, but the number varies a lot
+// between rays; run per segment, the wavefront waits for its slowest lane (measured ~1/3 lane
+// utilisation on the 50k-triangle scene).  Here the scheduling unit is ONE LEAF: every loop
+// iteration each traversing lane advances its own stack to its next leaf (node phase) and tests
+// that leaf's triangles (leaf phase); a lane whose stack is empty finishes its segment (spheres,
+// lights, shading) and starts the next segment or a new path at once, while the other lanes keep
+// walking.  Visit order per ray is unchanged, so the winner is the same triangle.
+template <bool STATS>
+__global__ void __launch_bounds__(kTraceBlock) k_trace_bvh(const KParams p) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const uint32_t total_items = tiles_x * tiles_y * S * 64u;
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    const uint32_t node_count = p.u.bvh_node_count;
+    const Cam cam = make_cam(p);
+    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
+    const cf4p nodes = (cf4p)p.nodes;
+    const cf4p ptris = (cf4p)p.ptris;
+    uint32_t* const stack = &s_stack[tid];
+    Tally<STATS> tl;
+
+    enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
+    uint32_t state = IDLE;
+    bool exhausted = false;
+    uint32_t item = 0, loc_next = 0, loc_end = 0;
+    const uint32_t batch = p.queue_batch;
+    Path pt;
+    pt.depth = 0;
+    TriHit th;
+    th.hit = false;
+    th.t = 1e20f;
+    th.u = th.v = 0.0f;
+    th.slot = 0u;
+    f3 inv = mk(0, 0, 0);
+    int sp = 0;
+
+    for (;;) {
+        // ---- (1) hand items to idle lanes (same scheme as k_trace)
+        unsigned long long idle = __ballot(state == IDLE);
+        for (int round = 0; round < 2 && idle != 0ull; round++) {
+            if (loc_next == loc_end) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(p.queue, batch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= total_items) {
+                    exhausted = true;
+                    break;
+                }
+                loc_next = b;
+                loc_end = (total_items - b < batch) ? total_items : b + batch;
+            }
+            const uint32_t avail = loc_end - loc_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = (state == IDLE) && rank < avail;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t taken = n_idle < avail ? n_idle : avail;
+            if (take) {
+                const uint32_t it = loc_next + rank;
+                const uint32_t in = it & 63u, ts = it >> 6;
+                const uint32_t tile = ts / S, smp = ts - tile * S;
+                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
+                bool ok = (x < width) && (ly < p.local_rows);
+                uint32_t y = 0;
+                if (ok) {
+                    y = global_row(p, ly);
+                    ok = y < p.u.height;
+                }
+                if (ok) {
+                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                    item = it;
+                    if (p.u.max_depth > 0u) {
+                        state = BEGIN;
+                    } else {
+                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        tl.paths++;
+                    }
+                }
+            }
+            loc_next += taken;
+            idle = __ballot(state == IDLE);
+            if (taken == n_idle) break;
+        }
+        if (__ballot(state != IDLE) == 0ull) {
+            if (exhausted && loc_next == loc_end) break;
+            continue;
+        }
+
+        // ---- (2) start of a segment: reset the traversal (shader.wgsl:283-307)
+        if (state == BEGIN) {
+            th.hit = false;
+            th.t = 1e20f;
+            th.u = th.v = 0.0f;
+            th.slot = 0u;
+            inv = mk(1.0f / pt.d.x, 1.0f / pt.d.y, 1.0f / pt.d.z);
+            stack[0] = 0u;
+            sp = 1;
+            state = TRAV;
+        }
+
+        // ---- (3) node phase: pop until this lane has a leaf to test or its stack is empty
+        uint32_t first = 0, count = 0;
+        while (state == TRAV && count == 0u) {
+            if (sp == 0) {
+                state = FINISH;
+                break;
+            }
+            sp--;
+            const uint32_t node_idx = stack[sp * kTraceBlock];
+            if (node_idx >= node_count) continue;
+            const v4f n0 = nodes[node_idx * 3u], n1 = nodes[node_idx * 3u + 1u];
+            const v4u n2 = ((cu4p)p.nodes)[node_idx * 3u + 2u];
+            if constexpr (STATS) tl.nodes++;
+            if (!isect_aabb(pt.o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
+            if (n2.w > 0u) {
+                first = n2.z;
+                count = n2.w;
+            } else {
+                if (n2.x < node_count) {
+                    stack[sp * kTraceBlock] = n2.x;
+                    sp++;
+                }
+                if (n2.y < node_count) {
+                    stack[sp * kTraceBlock] = n2.y;
+                    sp++;
+                }
+            }
+        }
+
+        // ---- (4) leaf phase: this lane's leaf, triangle by triangle (shader.wgsl:327-374)
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t slot = first + i;
+            if (slot >= p.index_len) continue;
+            const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+            if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+            if constexpr (STATS) tl.tris++;
+            const float before = th.t;
+            test_slot(a, b, c, slot, pt.o, pt.d, th);
+            if constexpr (STATS) tl.mesh_hits += (th.t != before) ? 1u : 0u;
+        }
+
+        // ---- (5) traversal complete: ground, spheres, lights, shading, next ray
+        if (state == FINISH) {
+            const bool alive = segment_finish<STATS>(p, pt, th, tl);
+            if (alive) {
+                state = BEGIN;
+            } else {
+                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                tl.paths++;
+                state = IDLE;
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
 // Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,
 // lane = pixel; each sample row is a contiguous 1 KiB read.
 __global__ void __launch_bounds__(256) k_accumulate(const KParams p) {
@@ -1095,10 +1264,17 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         q.queue_batch = (uint32_t)batch;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
-        if (stats)
+        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
+        if (stepped) {
+            if (stats)
+                hipLaunchKernelGGL(k_trace_bvh<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
+            else
+                hipLaunchKernelGGL(k_trace_bvh<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        } else if (stats) {
             hipLaunchKernelGGL(k_trace<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
-        else
+        } else {
             hipLaunchKernelGGL(k_trace<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((tiles + 3u) / 4u)), dim3(256), 0, stream, p);

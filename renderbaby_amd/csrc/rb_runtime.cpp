@@ -386,6 +386,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];
+    p.no_leaf_stepping = e->opt._reserved[3];
     return p;
 }
 

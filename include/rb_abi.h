@@ -226,7 +226,8 @@ enum {
 };
 
 enum {
-    RB_FLAG_STATS = 1u  /* count nodes/tris/spheres/lights per segment (slower) */
+    RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
+    RB_FLAG_NO_SPHERE_BVH = 2u /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.
@@ -242,7 +243,9 @@ typedef struct rb_stats {
     uint64_t lights_tested;
     uint64_t mesh_hits;
     uint64_t launches;
-    double kernel_ms; /* sum of HIP-event durations of the render launches */
+    double kernel_ms; /* sum of HIP-event durations of the render launch groups */
+    double trace_ms;  /* of which: the trace / render kernels alone (k_trace*, k_queue, k_pixel) */
+    double accumulate_ms; /* of which: k_accumulate (RB_KERNEL_STREAM only) */
 } rb_stats;
 
 /* ------------------------------------------------------------------------ */
@@ -348,6 +351,10 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
  * dot on n input pairs (out8n: 8*n floats) so tests can check them against
  * IEEE-754 results computed on the host. */
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
+
+/* Name of the render kernel the most recent rb_dispatch used ("k_trace", "k_trace_bvh",
+ * "k_queue", "k_pixel"). */
+const char* rb_last_kernel_name(const rb_engine* e);
 
 /* Library / device identification for logs. */
 const char* rb_version(void);

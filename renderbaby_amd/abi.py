@@ -61,6 +61,7 @@ RB_ERR_NO_MORE_FRAMES = 12
 
 KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_QUEUE, KERNEL_STREAM = 0, 1, 2, 3
 FLAG_STATS = 1
+FLAG_NO_SPHERE_BVH = 2
 
 
 class Field(C.Structure):
@@ -86,7 +87,7 @@ class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("paths", C.c_uint64), ("nodes_popped", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("spheres_tested", C.c_uint64),
                 ("lights_tested", C.c_uint64), ("mesh_hits", C.c_uint64), ("launches", C.c_uint64),
-                ("kernel_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("accumulate_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

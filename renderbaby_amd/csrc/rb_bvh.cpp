@@ -136,4 +136,79 @@ bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_st
     return true;
 }
 
+
+// ---------------------------------------------------------------- sphere BVH --
+// The reference scans every sphere on every segment (shader.wgsl:574-586), which is
+// intractable beyond a few thousand spheres (BASELINE config C4 has 10^6).  This builds
+// a binary tree over the spheres' tight boxes (median split on the longest axis of the
+// centroid bounds, <= 4 spheres per leaf).  A node stores BOTH children's boxes, so one
+// visit decides both; the traversal (rb_kernels.hip, intersect_spheres_bvh) inflates the
+// boxes per ray by a margin that covers the rounding error of the reference's own
+// discriminant, runs the reference's exact intersect_sphere on every candidate and
+// breaks ties by the lower original index -- the winner of the linear scan.
+namespace {
+struct SBuilder {
+    const rb_sphere* sph;
+    std::vector<uint32_t>& order;
+    std::vector<SphereNode>& nodes;
+    uint32_t max_depth = 0;
+
+    void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::numeric_limits<float>::infinity();
+            mx[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (size_t i = first; i < first + count; ++i) {
+            const rb_sphere& s = sph[order[i]];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], s.center[a] - s.radius);
+                mx[a] = std::max(mx[a], s.center[a] + s.radius);
+            }
+        }
+    }
+    // returns a child reference: leaf = 0x80000000 | (count-1) << 28 | first ; node = index
+    uint32_t build(size_t first, size_t count, uint32_t depth) {
+        max_depth = std::max(max_depth, depth);
+        if (count <= 4) return 0x80000000u | (static_cast<uint32_t>(count - 1) << 28) | static_cast<uint32_t>(first);
+        float cmn[3], cmx[3];
+        for (int a = 0; a < 3; ++a) {
+            cmn[a] = std::numeric_limits<float>::infinity();
+            cmx[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (size_t i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                cmn[a] = std::min(cmn[a], sph[order[i]].center[a]);
+                cmx[a] = std::max(cmx[a], sph[order[i]].center[a]);
+            }
+        const float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
+        const int axis = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);
+        const size_t mid = first + count / 2;
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                         [&](uint32_t a, uint32_t b) { return sph[a].center[axis] < sph[b].center[axis]; });
+        const uint32_t me = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        SphereNode n;
+        bounds(first, mid - first, n.lmin, n.lmax);
+        bounds(mid, first + count - mid, n.rmin, n.rmax);
+        n.left = build(first, mid - first, depth + 1);
+        n.right = build(mid, first + count - mid, depth + 1);
+        n._pad0 = n._pad1 = 0;
+        nodes[me] = n;
+        return me;
+    }
+};
+}  // namespace
+
+void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode>& nodes,
+                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
+                      float bmax[3]) {
+    nodes.clear();
+    order.resize(n);
+    for (size_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
+    SBuilder b{spheres, order, nodes};
+    b.bounds(0, n, bmin, bmax);
+    *root_ref = n ? b.build(0, n, 1) : 0x80000000u;
+    *depth = b.max_depth + 1;
+}
+
 }  // namespace rb

@@ -20,6 +20,23 @@ void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_no
 bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_stack, std::string& why,
                   uint32_t* depth_out);
 
+// Sphere acceleration structure (no reference counterpart; see rb_bvh.cpp).  64 B per node.
+struct alignas(16) SphereNode {
+    float lmin[3];
+    uint32_t left;    // child reference: node index, or leaf = 0x80000000 | (count-1) << 28 | first
+    float lmax[3];
+    uint32_t right;
+    float rmin[3];
+    uint32_t _pad0;
+    float rmax[3];
+    uint32_t _pad1;
+};
+static_assert(sizeof(SphereNode) == 64, "SphereNode is 64 B");
+constexpr uint32_t kSphereBvhThreshold = 64;  // use the linear two-pass scan up to this many spheres
+void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode>& nodes,
+                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
+                      float bmax[3]);
+
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {
     C_SEGMENTS = 0, C_PATHS, C_NODES, C_TRIS, C_SPHERES, C_LIGHTS, C_MESH_HITS, C_COUNT
@@ -61,6 +78,13 @@ struct KParams {
     const uint32_t* tex_data;
     const rb_texture_info* tex_info;
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
+    const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
+    const float* sph_leaf;         // float4 {centre, radius} in leaf order
+    const uint32_t* sph_id;        // original sphere index per leaf-order slot
+    float sph_bmin[3];             // bounds of all spheres (for the per-ray error margin)
+    uint32_t sph_root;             // root child reference
+    float sph_bmax[3];
+    uint32_t _pad_sph;
     float* accum;                  // local_rows_padded * width * 4
     uint32_t* out_rgba;            // local_rows_padded * width, x mirrored
     unsigned long long* counters;  // C_COUNT
@@ -82,11 +106,13 @@ struct KParams {
 struct LaunchInfo {
     uint32_t grid, block;
     size_t lds_bytes;
+    const char* kernel_name;
 };
 
 // ---- rb_kernels.hip
 // All return hipError_t as int (0 = success); launches are asynchronous on `stream`.
-int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream, LaunchInfo* info);
+int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream, LaunchInfo* info,
+                  void* ev_after_trace = nullptr);
 int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
                      uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);

@@ -411,13 +411,99 @@ DEV bool near_zero(f3 v) {                                                // :46
     return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
 }
 
+// Sphere acceleration structure (rb_bvh.cpp, sphere_bvh_build): closest sphere with the
+// semantics of the reference's linear scan (shader.wgsl:574-586).
+//  * every candidate is evaluated with the reference's exact intersect_sphere;
+//  * the scan accepts `t > 0.001 && t < closest.t` in index order, i.e. the winner is the
+//    smallest t below the incoming closest_t, ties going to the lowest index: here
+//    `t < best || (t == best && id < best_id)`;
+//  * a subtree is skipped only if the ray misses its box inflated by m, or enters it beyond
+//    best_t.  m covers the rounding error of the reference's own arithmetic: its discriminant
+//    hb^2 - a*(|oc|^2 - r^2) carries an absolute error <= 16 u a |oc|^2 (u = 2^-24), so a sphere
+//    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 D^2) from its centre and the
+//    reported t can be early by about the same amount; D = the farthest the ray origin can be
+//    from any sphere.  m = 3e-3 * D (> 2 * sqrt(1e-6) * D) bounds both.
+DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx,
+                               uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
+    const cf4p nodes = (cf4p)p.sph_nodes;
+    const cf4p leafs = (cf4p)p.sph_leaf;
+    const RB_CONST uint32_t* ids = cptr(p.sph_id);
+    const f3 bmin = ld3(p.sph_bmin), bmax = ld3(p.sph_bmax);
+    const float dx = fmaxf(fabsf(o.x - bmin.x), fabsf(o.x - bmax.x));
+    const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
+    const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
+    const float m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float best = closest_t;
+    uint32_t best_id = 0xFFFFFFFFu;
+
+    // slab test of a box inflated by m: visit unless missed or entered beyond `best`
+    // (comparisons are written so that a NaN means "visit")
+    auto entry = [&](v4f lo, v4f hi, float& tn) -> bool {
+        const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
+        const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
+        tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+        const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+        return !(tf < fmaxf(tn, 0.0f)) && !(tn > best);
+    };
+    auto leaf = [&](uint32_t ref) {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
+        for (uint32_t j = first; j < first + count; j++) {
+            const v4f cr = leafs[j];
+            const uint32_t id = ids[j];
+            if (n_tested) (*n_tested)++;
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && (t < best || (t == best && id < best_id))) {
+                best = t;
+                best_id = id;
+            }
+        }
+    };
+
+    uint32_t cur = p.sph_root;
+    int sp = 0;
+    for (;;) {
+        if (cur & 0x80000000u) {
+            leaf(cur);
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+            continue;
+        }
+        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+        float tl_, tr_;
+        const bool hl = entry(l0, l1, tl_), hr = entry(r0, r1, tr_);
+        if (hl && hr) {
+            // nearer child first; the other waits on the stack
+            const bool left_first = !(tr_ < tl_);
+            stack[sp * stride] = left_first ? rref : lref;
+            sp++;
+            cur = left_first ? lref : rref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+        }
+    }
+    if (best_id != 0xFFFFFFFFu) {
+        closest_t = best;
+        sphere_idx = best_id;
+    }
+}
+
 // One iteration of the bounce loop, shader.wgsl:534-660.  Returns true when the
 // path continues.  The closest-hit search keeps the reference's category order
 // (ground, BVH, spheres, lights) and strict comparisons, so ties resolve the
 // same way; per-hit data that only the final winner needs (position, normal,
 // material, uv) is produced once, after the search.
 template <bool STATS>
-DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, Tally<STATS>& tl) {
+DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
+                        Tally<STATS>& tl) {
     const f3 o = pt.o, d = pt.d;
     tl.segments++;
 
@@ -457,6 +543,11 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, Tally<STATS
     uint32_t sphere_idx = 0xFFFFFFFFu;
     const uint32_t ns = p.u.spheres_count;
     const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
+    if (p.sph_nodes != nullptr) {
+        unsigned long long* cnt = nullptr;
+        if constexpr (STATS) cnt = &tl.spheres;
+        intersect_spheres_bvh(p, o, d, a, closest_t, sphere_idx, stack, stride, cnt);
+    } else
     for (uint32_t base = 0; base < ns; base += 32u) {
         const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
         uint32_t cand = 0u;
@@ -651,7 +742,7 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
         asm volatile("" ::"v"(th2.t), "v"(th2.slot));
     }
 #endif
-    return segment_finish<STATS>(p, pt, th, tl);
+    return segment_finish<STATS>(p, pt, th, stack, stride, tl);
 }
 
 // ----------------------------------------------------------------- camera --
@@ -1105,7 +1196,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_bvh(const KParams p) {
 
         // ---- (5) traversal complete: ground, spheres, lights, shading, next ray
         if (state == FINISH) {
-            const bool alive = segment_finish<STATS>(p, pt, th, tl);
+            const bool alive = segment_finish<STATS>(p, pt, th, stack, kTraceBlock, tl);
             if (alive) {
                 state = BEGIN;
             } else {
@@ -1222,7 +1313,7 @@ static uint32_t persistent_blocks(uint64_t items, uint32_t block, uint32_t block
     return blocks;
 }
 
-int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info) {
+int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info, void* ev_after_trace) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LaunchInfo li{};
     const size_t lds = sizeof(uint32_t) * p.stack_depth * 256u;
@@ -1231,6 +1322,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         const uint32_t tiles_x = (p.u.width + 15u) / 16u, tiles_y = (p.local_rows + 15u) / 16u;
         li.grid = tiles_x * tiles_y;
         li.block = kPixelBlock;
+        li.kernel_name = "k_pixel";
         if (li.grid == 0) return 0;
         if (stats)
             hipLaunchKernelGGL(k_pixel<true>, dim3(li.grid), dim3(li.block), lds, stream, p);
@@ -1240,6 +1332,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         const uint64_t items = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u) * 64u;
         li.grid = persistent_blocks(items, kQueueBlock, p.blocks_per_cu ? p.blocks_per_cu : 8u);  // residency is set by VGPRs
         li.block = kQueueBlock;
+        li.kernel_name = "k_queue";
         if (li.grid == 0) return 0;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
@@ -1265,6 +1358,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
         const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
+        li.kernel_name = stepped ? "k_trace_bvh" : "k_trace";
         if (stepped) {
             if (stats)
                 hipLaunchKernelGGL(k_trace_bvh<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
@@ -1277,6 +1371,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         }
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
+        if (ev_after_trace) (void)hipEventRecord(static_cast<hipEvent_t>(ev_after_trace), stream);
         hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((tiles + 3u) / 4u)), dim3(256), 0, stream, p);
     }
     if (info) *info = li;

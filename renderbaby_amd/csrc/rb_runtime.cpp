@@ -55,6 +55,9 @@ struct rb_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;   // per launch chunk: begin, after-trace, end
+    uint32_t ev_used = 0;
+    const char* last_kernel_name = "";
     rb_options opt{};
 
     bool initialized = false;        // GpuWrapper::initialized (gpu_wrapper.rs:69,117)
@@ -86,6 +89,12 @@ struct rb_engine {
     DevBuf<uint32_t> out_rgba;
     DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> queue;
+    DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
+    DevBuf<float> sph_leaf;
+    DevBuf<uint32_t> sph_id;
+    uint32_t sph_root = 0, sph_depth = 0;
+    float sph_bmin[3] = {0, 0, 0}, sph_bmax[3] = {0, 0, 0};
+    bool sph_bvh = false;
     DevBuf<float> colors;            // RB_KERNEL_STREAM: float4 per (pixel, sample) of one launch chunk
     uint32_t bvh_stack = 0;          // traversal-stack entries the current tree needs
 
@@ -256,6 +265,32 @@ int upload_textures(rb_engine* e, const rb_field& f) {
     return RB_OK;
 }
 
+// Spheres beyond kSphereBvhThreshold get the library's own acceleration structure; the
+// reference's linear scan (shader.wgsl:574-586) stays the rule for small counts.
+int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
+    e->sph_bvh = false;
+    if (n <= rb::kSphereBvhThreshold || n >= (1u << 28) || (e->opt.flags & RB_FLAG_NO_SPHERE_BVH)) return RB_OK;
+    std::vector<rb::SphereNode> nodes;
+    std::vector<uint32_t> order;
+    rb::sphere_bvh_build(s, n, nodes, order, &e->sph_root, &e->sph_depth, e->sph_bmin, e->sph_bmax);
+    if (e->sph_depth > rb::kStackDepth) return RB_OK;  // degenerate input: keep the linear scan
+    std::vector<float> leaf(n * 4);
+    for (size_t j = 0; j < n; ++j) {
+        const rb_sphere& sp = s[order[j]];
+        leaf[j * 4 + 0] = sp.center[0];
+        leaf[j * 4 + 1] = sp.center[1];
+        leaf[j * 4 + 2] = sp.center[2];
+        leaf[j * 4 + 3] = sp.radius;
+    }
+    int rc = upload(e, e->sph_nodes, nodes.data(), nodes.size(), nullptr, true);
+    if (!rc) rc = upload(e, e->sph_leaf, leaf.data(), leaf.size(), nullptr, true);
+    if (!rc) rc = upload(e, e->sph_id, order.data(), order.size(), nullptr, true);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));  // the vectors above are locals
+    e->sph_bvh = true;
+    return RB_OK;
+}
+
 // Applies one non-uniform field.  `first` = the engine's first update
 // (gpu_wrapper.rs:117-163: only Create is acted on); otherwise :196-294.
 int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
@@ -273,7 +308,11 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
     const size_t n = del ? 0 : f.count;
     int rc = RB_OK;
     switch (idx) {
-        case 1: rc = upload(e, e->spheres, src, n, nullptr, true); e->n_spheres = static_cast<uint32_t>(n); break;
+        case 1:
+            rc = upload(e, e->spheres, src, n, nullptr, true);
+            e->n_spheres = static_cast<uint32_t>(n);
+            if (!rc) rc = build_sphere_bvh(e, static_cast<const rb_sphere*>(src), n);
+            break;
         case 2: rc = upload(e, e->uvs, src, n, nullptr, true); e->n_uvs = static_cast<uint32_t>(n); break;
         case 3: rc = upload(e, e->meshes, src, n, nullptr, true); e->n_meshes = static_cast<uint32_t>(n); break;
         case 4:
@@ -382,8 +421,18 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.stripe_rows = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     p.local_rows = e->local_rows;
     p.colors = e->colors.ptr;
+    const bool use_sph_bvh = e->sph_bvh && p.u.spheres_count == e->n_spheres;
+    p.sph_nodes = use_sph_bvh ? e->sph_nodes.ptr : nullptr;
+    p.sph_leaf = e->sph_leaf.ptr;
+    p.sph_id = e->sph_id.ptr;
+    p.sph_root = e->sph_root;
+    for (int i = 0; i < 3; ++i) {
+        p.sph_bmin[i] = e->sph_bmin[i];
+        p.sph_bmax[i] = e->sph_bmax[i];
+    }
     // a single-node tree is walked without a stack (rb_kernels.hip, intersect_bvh)
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
+    if (use_sph_bvh) p.stack_depth = std::max(p.stack_depth, e->sph_depth);
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];
     p.no_leaf_stepping = e->opt._reserved[3];
@@ -426,12 +475,30 @@ int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     }
     HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
     uint32_t launches = 0;
+    e->ev_used = 0;
     for (uint32_t done = 0; done < n_passes;) {
         const uint32_t n = std::min(chunk, n_passes - done);
         rb::KParams p = make_params(e, first_pass + done, n);
         rb::LaunchInfo li{};
-        rc = rb::launch_render(p, kernel, stats, e->stream, &li);
+        // per-chunk timing events (first 256 chunks of a group; later ones only count in the total)
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        if (e->ev_used + 3 <= 768) {
+            while (e->ev_pool.size() < e->ev_used + 3) {
+                hipEvent_t x;
+                HIP_TRY(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
+            for (int i = 0; i < 3; ++i) ev[i] = e->ev_pool[e->ev_used + i];
+            e->ev_used += 3;
+            HIP_TRY(e, hipEventRecord(ev[0], e->stream));
+        }
+        rc = rb::launch_render(p, kernel, stats, e->stream, &li, ev[1]);
         if (rc) return fail(e, RB_ERR_DEVICE, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (ev[2]) {
+            if (kernel != RB_KERNEL_STREAM) HIP_TRY(e, hipEventRecord(ev[1], e->stream));
+            HIP_TRY(e, hipEventRecord(ev[2], e->stream));
+        }
+        if (li.kernel_name) e->last_kernel_name = li.kernel_name;
         done += n;
         launches++;
     }
@@ -464,6 +531,13 @@ int accumulate_timing(rb_engine* e) {
     e->last_dispatch_ms = ms;
     if (e->timing_pending) {
         e->stats.kernel_ms += ms;
+        for (uint32_t i = 0; i + 3 <= e->ev_used; i += 3) {
+            float t = 0.0f, a = 0.0f;
+            HIP_TRY(e, hipEventElapsedTime(&t, e->ev_pool[i], e->ev_pool[i + 1]));
+            HIP_TRY(e, hipEventElapsedTime(&a, e->ev_pool[i + 1], e->ev_pool[i + 2]));
+            e->stats.trace_ms += t;
+            e->stats.accumulate_ms += a;
+        }
         e->timing_pending = false;
     }
     return RB_OK;
@@ -586,6 +660,7 @@ void rb_destroy(rb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    for (hipEvent_t x : e->ev_pool) (void)hipEventDestroy(x);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -822,6 +897,8 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris, rb_bvh_node* nodes_
 }
 
 const char* rb_version(void) { return "renderbaby-hip 0.1 (gfx950)"; }
+
+const char* rb_last_kernel_name(const rb_engine* e) { return e ? e->last_kernel_name : ""; }
 
 int rb_device_name(int device, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0) return RB_ERR_NULL_ARGUMENT;

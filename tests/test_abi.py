@@ -32,7 +32,7 @@ def test_layout_sizes_and_offsets():
     t = {k: abi.GPU_TRIANGLE.fields[k][1] for k in abi.GPU_TRIANGLE.names}
     assert (t["v0"], t["v0_index"], t["v1"], t["v1_index"], t["v2"], t["v2_index"], t["mesh_index"]) == (0, 12, 16, 28, 32, 44, 48)
     assert C.sizeof(abi.Field) == 24 and C.sizeof(abi.Config) == 9 * 24
-    assert C.sizeof(abi.Options) == 48 and C.sizeof(abi.Stats) == 72
+    assert C.sizeof(abi.Options) == 48 and C.sizeof(abi.Stats) == 88
 
 
 def test_library_exports_every_declared_symbol():

@@ -145,3 +145,19 @@ def test_sharded_engines_reassemble_the_single_gpu_frame(kernel, world, stripe_r
         eng.close()
     frame = rdist.assemble(parts, s.height, stripe_rows).numpy()
     assert np.array_equal(frame, full)
+
+
+@pytest.mark.parametrize("n,extent,size", [(200, 6.0, 64), (10_000, 25.0, 192)])
+def test_sphere_bvh_matches_the_linear_scan(n, extent, size):
+    # BASELINE C4 scaled down: the library's sphere acceleration structure must give
+    # exactly the linear scan's winner (oracle = reference algorithm, O(N) per segment)
+    s = scenes.spheres_scene(n=n, width=size, height=size, spp=2, max_depth=5, extent=extent)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    for kw in (dict(), dict(no_sphere_bvh=True)):
+        frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=False, **kw)
+        bad = np.argwhere(acc.view(np.uint32) != o_acc.view(np.uint32))
+        assert len(bad) == 0, (kw, len(bad), bad[:4])
+        assert np.array_equal(frame.pixels, o_rgba)
+        assert st["segments"] == o_st["segments"]
+    # the hit rate must be meaningful for the comparison to mean anything
+    assert (o_acc[..., :3].sum(-1) > 0).mean() > 0.5

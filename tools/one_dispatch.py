@@ -9,6 +9,9 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 if w == "c1": s = scenes.cornell(512, 512, spp, 4)
 elif w == "c2": s = scenes.cornell(1920, 1080, spp, 8)
 elif w == "c3": s = scenes.mesh_scene(112, 112, 1920, 1080, spp, 5)
+elif w == "c4": s = scenes.spheres_scene(1_000_000, 4096, 4096, spp, 5)
+elif w == "c4s": s = scenes.spheres_scene(1_000_000, 1024, 1024, spp, 5)
+elif w == "c5s": s = scenes.mesh_scene(1024, 512, 1920, 1080, spp, 16, seed=11, with_blob=False)
 rc = RenderConfig.from_scene(s)
 eng = Engine.new(rc, kernel=kern); eng.update(rc)
 for _ in range(reps):

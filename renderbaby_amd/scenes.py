@@ -320,7 +320,8 @@ def blob_tris(nu, nv, seed, center=(0.0, 2.6, -6.0), radius=1.6, bump=0.25):
     X = center[0] + r * np.sin(Pn) * np.cos(T)
     Y = center[1] + r * np.cos(Pn)
     Z = center[2] + r * np.sin(Pn) * np.sin(T)
-    return _grid_tris(np.stack([X, Y, Z], axis=-1).astype(np.float32))
+    t = _grid_tris(np.stack([X, Y, Z], axis=-1).astype(np.float32))
+    return np.ascontiguousarray(t[:, ::-1, :])  # outward-facing winding (normals are never flipped, shader.wgsl:351)
 
 
 def _light_quad(y=7.0, half=2.0, zc=-6.0):

@@ -51,7 +51,7 @@ struct DevBuf {
 
 struct rb_engine {
     std::mutex mu;
-    std::string error;
+    mutable std::string error;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -735,7 +735,10 @@ void rb_iter_destroy(rb_engine* e) { (void)e; }  // lib.rs:231-233: logs only
 
 int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
-    if (!e->have_uniforms) return RB_ERR_UNIFORMS_NOT_INITIALIZED;
+    if (!e->have_uniforms) {
+        e->error = "Uniforms must be initialized";  // gpu_wrapper.rs:313,321
+        return RB_ERR_UNIFORMS_NOT_INITIALIZED;
+    }
     if (width) *width = e->width;
     if (height) *height = e->height;
     return RB_OK;

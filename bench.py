@@ -4,8 +4,9 @@
 Workload (BASELINE.json configs[1], "C2"): the seeded procedural Cornell box
 (12 triangles incl. the emissive ceiling quad, 8 spheres, 0 point lights),
 1920x1080, 1024 spp, max_depth 8.  A *step* is one full render of that frame:
-every pixel accumulates all 1024 samples in one launch of the hot kernel, with
-the scene already resident in HBM.  metric = Msamples/s where a sample is one
+every pixel accumulates all 1024 samples, with the scene already resident in HBM
+(the (pixel, sample) stream is cut into a few launches of the trace kernel so its
+per-path colour buffer stays within a 4 GiB budget: `roofline.launches_per_step`).  metric = Msamples/s where a sample is one
 ray segment (one executed iteration of the bounce loop, shader.wgsl:534),
 counted on the device and equal to the oracle's count.
 
@@ -41,6 +42,10 @@ def parse():
     ap.add_argument("--stripe-rows", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.achieved = null)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo (+ --same-device) rehearses the N>1 path on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--dump-frame", default="", help="rank 0 writes the last assembled RGBA8 frame to this .npy")
     return ap.parse_args()
 
 
@@ -114,9 +119,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the render path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = f"cuda:{local_rank}" if a.backend == "nccl" else "cpu"
 
     from renderbaby_amd import abi, engine
     from renderbaby_amd.dist import ShardedRenderer
@@ -138,15 +149,17 @@ def main():
         stats = r.engine.stats()
         r.close()
 
-    r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel)
+    r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel,
+                        host_gather=(a.backend != "nccl"))
     for _ in range(a.warmup):
         r.step()
     r.engine.reset_stats()
     kernel_ms = []
     barrier()
     t0 = time.perf_counter()
+    frame = None
     for _ in range(a.steps):
-        r.step()
+        frame = r.step()
         kernel_ms.append(r.engine.last_dispatch_ms())  # HIP events on the engine's stream
     barrier()
     elapsed = time.perf_counter() - t0
@@ -155,14 +168,17 @@ def main():
     seg_per_step = st["segments"] // max(a.steps, 1)
     paths_per_step = st["paths"] // max(a.steps, 1)
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    cnt = torch.tensor([float(seg_per_step), float(paths_per_step)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([float(seg_per_step), float(paths_per_step)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     seg_total, paths_total = float(cnt[0].item()), float(cnt[1].item())
 
+    if rank == 0 and a.dump_frame and frame is not None:
+        import numpy as np
+        np.save(a.dump_frame, frame.cpu().numpy())
     if rank == 0:
         value = seg_total * a.steps / elapsed / 1e6
         # dominant kernel: the trace kernel.  A step is `launches` launches of it (the (pixel,
@@ -191,7 +207,7 @@ def main():
             roof["traffic"] = tr.get("hbm_bytes_per_launch")
             roof["traffic_source"] = tr.get("source")
         cpu = None
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:
             cpu = cpu_baseline(scene, a.cpu_seconds)
         out = {
             "metric": "Msamples/s (ray-segments/s)", "value": value, "unit": "Msamples/s",

@@ -279,6 +279,58 @@ DEV void test_slot(const v4f a, const v4f b, const v4f c, uint32_t slot, f3 o, f
     }
 }
 
+#ifndef RB_TRI_PAIRS
+#define RB_TRI_PAIRS 1
+#endif
+// Two triangles per step with packed f32 math (v_pk_mul_f32 / v_pk_add_f32: two IEEE
+// binary32 operations per lane per instruction).  Element 0 is the triangle at `slot`,
+// element 1 the one at `slot + 1`; every element goes through exactly the operations of
+// isect_triangle (shader.wgsl:248-280), so each t, u, v is bit-identical to the one-at-a-time
+// form, and the two candidates are offered to the closest-hit test in slot order.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool STATS>
+DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f a1, const v4f b1, const v4f c1,
+                   bool ok1, uint32_t slot, f3 o, f3 d, TriHit& h, Tally<STATS>& tl) {
+    const f2 v0x = {a0.x, a1.x}, v0y = {a0.y, a1.y}, v0z = {a0.z, a1.z};
+    const f2 e1x = {b0.x, b1.x}, e1y = {b0.y, b1.y}, e1z = {b0.z, b1.z};
+    const f2 e2x = {c0.x, c1.x}, e2y = {c0.y, c1.y}, e2z = {c0.z, c1.z};
+    // h = cross(d, edge2)
+    const f2 hx = d.y * e2z - d.z * e2y;
+    const f2 hy = d.z * e2x - d.x * e2z;
+    const f2 hz = d.x * e2y - d.y * e2x;
+    const f2 a = (e1x * hx + e1y * hy) + e1z * hz;
+    const f2 f = {1.0f / a.x, 1.0f / a.y};
+    const f2 sx = o.x - v0x, sy = o.y - v0y, sz = o.z - v0z;
+    const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
+    // q = cross(s, edge1)
+    const f2 qx = sy * e1z - sz * e1y;
+    const f2 qy = sz * e1x - sx * e1z;
+    const f2 qz = sx * e1y - sy * e1x;
+    const f2 v = f * ((d.x * qx + d.y * qy) + d.z * qz);
+    const f2 t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    const f2 uv = u + v;
+    const bool hit0 = ok0 && !(fabsf(a.x) < 1e-6f) && !(u.x < 0.0f) && !(u.x > 1.0f) && !(v.x < 0.0f) && !(uv.x > 1.0f) &&
+                      (t.x > 0.0f);
+    const bool hit1 = ok1 && !(fabsf(a.y) < 1e-6f) && !(u.y < 0.0f) && !(u.y > 1.0f) && !(v.y < 0.0f) && !(uv.y > 1.0f) &&
+                      (t.y > 0.0f);
+    if (hit0 && t.x > 0.001f && t.x < h.t) {
+        h.hit = true;
+        h.t = t.x;
+        h.u = u.x;
+        h.v = v.x;
+        h.slot = slot;
+        if constexpr (STATS) tl.mesh_hits++;
+    }
+    if (hit1 && t.y > 0.001f && t.y < h.t) {
+        h.hit = true;
+        h.t = t.y;
+        h.u = u.y;
+        h.v = v.y;
+        h.slot = slot + 1u;
+        if constexpr (STATS) tl.mesh_hits++;
+    }
+}
+
 template <bool STATS>
 DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     TriHit h;
@@ -304,19 +356,28 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
         const uint32_t first = n2.z, count = n2.w;
         const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
         if (first < end && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
-            v4f a = ptris[first * 4u], b = ptris[first * 4u + 1u], c = ptris[first * 4u + 2u];
+#if RB_TRI_PAIRS
+            uint32_t slot = first;
+            for (; slot + 2u <= end; slot += 2u) {
+                const v4f a0 = ptris[slot * 4u], b0 = ptris[slot * 4u + 1u], c0 = ptris[slot * 4u + 2u];
+                const v4f a1 = ptris[slot * 4u + 4u], b1 = ptris[slot * 4u + 5u], c1 = ptris[slot * 4u + 6u];
+                const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
+                if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
+                const float before = h.t;
+                test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, o, d, h, tl);
+                (void)before;
+            }
+            for (; slot < end; slot++) {
+#else
             for (uint32_t slot = first; slot < end; slot++) {
-                const uint32_t nx = (slot + 1u < end) ? slot + 1u : slot;
-                const v4f na = ptris[nx * 4u], nb = ptris[nx * 4u + 1u], nc = ptris[nx * 4u + 2u];
+#endif
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
                 if (__float_as_uint(c.w) != 0u) {  // guard :336
                     if constexpr (STATS) tl.tris++;
                     const float before = h.t;
                     test_slot(a, b, c, slot, o, d, h);
                     if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
                 }
-                a = na;
-                b = nb;
-                c = nc;
             }
         }
         return h;
@@ -948,9 +1009,12 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
 // shader.wgsl:712-717), then tone-maps and packs (:720-722).  Phase 2 is a
 // coalesced 1 KiB-per-wave stream and is HBM-bound; phase 1 is ALU-bound.
 constexpr uint32_t kTraceBlock = 256;
+#ifndef RB_TRACE_WAVES
+#define RB_TRACE_WAVES 6
+#endif
 
 template <bool STATS>
-__global__ void __launch_bounds__(kTraceBlock) k_trace(const KParams p) {
+__global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KParams p) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;

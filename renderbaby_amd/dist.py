@@ -63,12 +63,13 @@ class ShardedRenderer:
     [H, W, 4] uint8 tensor there, None elsewhere)."""
 
     def __init__(self, scene, rank=0, world=1, device=0, stripe_rows=DEFAULT_STRIPE_ROWS, kernel=0,
-                 passes_per_launch=0, stats=False):
+                 passes_per_launch=0, stats=False, host_gather=False):
         import torch
         from .engine import Engine, RenderConfig
         self.torch = torch
         self.scene, self.rank, self.world, self.device = scene, rank, world, device
         self.stripe_rows = stripe_rows
+        self.host_gather = host_gather  # gloo rehearsal: gather CPU copies instead of device memory
         rc = RenderConfig.from_scene(scene)
         self.engine = Engine.new(rc, device=device, shard_rank=rank, shard_count=world, stripe_rows=stripe_rows,
                                  kernel=kernel, passes_per_launch=passes_per_launch, stats=stats)
@@ -81,7 +82,8 @@ class ShardedRenderer:
         self.local = torch.as_tensor(_DevView(ptr, (rows, self.width, 4)), device=f"cuda:{device}")
         self.gather_list = None
         if world > 1 and rank == 0:
-            self.gather_list = [torch.empty_like(self.local) for _ in range(world)]
+            like = self.local.cpu() if host_gather else self.local
+            self.gather_list = [torch.empty_like(like) for _ in range(world)]
 
     def render_local(self):
         e = self.engine
@@ -94,7 +96,8 @@ class ShardedRenderer:
         if self.world == 1:
             return self.local
         import torch.distributed as dist
-        dist.gather(self.local, self.gather_list, dst=0)
+        src = self.local.cpu() if self.host_gather else self.local
+        dist.gather(src, self.gather_list, dst=0)
         if self.rank == 0:
             return assemble(self.gather_list, self.height, self.stripe_rows)
         return None

@@ -1,0 +1,41 @@
+"""Rehearsal of `bench.py --gpus 2` on a one-GPU box: two ranks launched by
+torch.distributed.run exactly as the driver does, both on cuda:0, with the gloo backend
+standing in for RCCL (two ranks cannot share one device under RCCL).  Everything else is
+the real N>1 path: stripe sharding in the engines, the gather, the assembly, the counters."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, nproc, tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", "29571"]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_reproduce_the_single_rank_frame(tmp_path):
+    common = ["--workload", "c1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+    one = _run(common + ["--gpus", "1", "--dump-frame", str(tmp_path / "one.npy")], 1, tmp_path)
+    two = _run(common + ["--gpus", "2", "--backend", "gloo", "--same-device", "--dump-frame", str(tmp_path / "two.npy")],
+               2, tmp_path)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["config"]["segments_per_step"] == two["config"]["segments_per_step"]
+    assert two["config"]["paths_per_step"] == 512 * 512 * 64
+    for j in (one, two):
+        assert j["unit"] == "Msamples/s" and j["value"] > 0 and j["roofline"]["achieved"] > 0
+        assert j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "strong"
+    assert np.array_equal(np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy"))

@@ -227,7 +227,9 @@ enum {
 
 enum {
     RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
-    RB_FLAG_NO_SPHERE_BVH = 2u /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
+    RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
+    RB_FLAG_FAST_BVH = 4u /* opt-in: walk the library's own SAH tree over the triangles (culling, near-first)
+                             and accept a hit only if the reference's traversal would have tested it */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.

@@ -62,6 +62,7 @@ RB_ERR_NO_MORE_FRAMES = 12
 KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_QUEUE, KERNEL_STREAM = 0, 1, 2, 3
 FLAG_STATS = 1
 FLAG_NO_SPHERE_BVH = 2
+FLAG_FAST_BVH = 4
 
 
 class Field(C.Structure):

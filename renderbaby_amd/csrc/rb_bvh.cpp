@@ -211,4 +211,196 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
     *depth = b.max_depth + 1;
 }
 
+
+// ------------------------------------------------------------ fast triangle tree --
+// Opt-in (RB_FLAG_FAST_BVH).  The reference walks its 128-triangle-leaf tree without
+// t-culling or ordering (shader.wgsl:282-392); on a 50k-triangle mesh that is ~430 triangle
+// tests per segment.  This builds a second tree over the SAME triangles (binned SAH, <= 4 per
+// leaf, both children's boxes in the parent) that the kernels walk near-child-first with
+// culling.  To keep the reference's winner it also emits, per triangle slot, the reference
+// leaf that holds it and its rank in the reference's visit order, plus a parent array of the
+// reference tree: an improving candidate is accepted only if every reference node from its
+// leaf up to the root passes the reference's own slab test, and equal t resolves by rank.
+namespace {
+struct FBuilder {
+    const std::vector<float>& bmn;   // per item: tight box min (3 floats)
+    const std::vector<float>& bmx;
+    std::vector<uint32_t>& items;    // permuted in place
+    std::vector<SphereNode>& nodes;
+    uint32_t limit;
+    uint32_t max_depth = 0;
+
+    void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::numeric_limits<float>::infinity();
+            mx[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (size_t i = first; i < first + count; ++i) {
+            const uint32_t it = items[i];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], bmn[it * 3 + a]);
+                mx[a] = std::max(mx[a], bmx[it * 3 + a]);
+            }
+        }
+    }
+    float centroid(uint32_t it, int a) const { return 0.5f * (bmn[it * 3 + a] + bmx[it * 3 + a]); }
+    static float area(const float mn[3], const float mx[3]) {
+        const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        return (x < 0 || y < 0 || z < 0) ? 0.0f : 2.0f * (x * y + y * z + z * x);
+    }
+
+    uint32_t build(size_t first, size_t count, uint32_t depth) {
+        max_depth = std::max(max_depth, depth);
+        if (count <= 2) return 0x80000000u | (static_cast<uint32_t>(count - 1) << 28) | static_cast<uint32_t>(first);
+        float cmn[3], cmx[3];
+        for (int a = 0; a < 3; ++a) {
+            cmn[a] = std::numeric_limits<float>::infinity();
+            cmx[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (size_t i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = centroid(items[i], a);
+                cmn[a] = std::min(cmn[a], c);
+                cmx[a] = std::max(cmx[a], c);
+            }
+        size_t mid = first + count / 2;
+        int split_axis = -1;
+        // levels left if we balance from here; switch to median splits before the stack limit
+        uint32_t need = 0;
+        for (size_t c = count; c > 2; c = (c + 1) / 2) ++need;
+        const bool force_median = depth + need + 2 >= limit;
+        if (!force_median) {
+            constexpr int B = 16;
+            float best = std::numeric_limits<float>::infinity();
+            int best_bin = -1;
+            for (int a = 0; a < 3; ++a) {
+                const float ext = cmx[a] - cmn[a];
+                if (!(ext > 0.0f)) continue;
+                uint32_t cnt[B] = {0};
+                float bmin_[B][3], bmax_[B][3];
+                for (int k = 0; k < B; ++k)
+                    for (int j = 0; j < 3; ++j) {
+                        bmin_[k][j] = std::numeric_limits<float>::infinity();
+                        bmax_[k][j] = -std::numeric_limits<float>::infinity();
+                    }
+                const float scale = B / ext;
+                for (size_t i = first; i < first + count; ++i) {
+                    const uint32_t it = items[i];
+                    int k = static_cast<int>((centroid(it, a) - cmn[a]) * scale);
+                    k = std::min(std::max(k, 0), B - 1);
+                    cnt[k]++;
+                    for (int j = 0; j < 3; ++j) {
+                        bmin_[k][j] = std::min(bmin_[k][j], bmn[it * 3 + j]);
+                        bmax_[k][j] = std::max(bmax_[k][j], bmx[it * 3 + j]);
+                    }
+                }
+                float lmn[3], lmx[3], rarea[B];
+                uint32_t rcnt[B];
+                float rmn[3], rmx[3];
+                for (int j = 0; j < 3; ++j) { rmn[j] = std::numeric_limits<float>::infinity(); rmx[j] = -rmn[j]; }
+                uint32_t acc = 0;
+                for (int k = B - 1; k >= 1; --k) {
+                    acc += cnt[k];
+                    for (int j = 0; j < 3; ++j) { rmn[j] = std::min(rmn[j], bmin_[k][j]); rmx[j] = std::max(rmx[j], bmax_[k][j]); }
+                    rcnt[k] = acc;
+                    rarea[k] = area(rmn, rmx);
+                }
+                for (int j = 0; j < 3; ++j) { lmn[j] = std::numeric_limits<float>::infinity(); lmx[j] = -lmn[j]; }
+                acc = 0;
+                for (int k = 0; k < B - 1; ++k) {
+                    acc += cnt[k];
+                    for (int j = 0; j < 3; ++j) { lmn[j] = std::min(lmn[j], bmin_[k][j]); lmx[j] = std::max(lmx[j], bmax_[k][j]); }
+                    if (acc == 0 || rcnt[k + 1] == 0) continue;
+                    const float cost = area(lmn, lmx) * acc + rarea[k + 1] * rcnt[k + 1];
+                    if (cost < best) { best = cost; best_bin = k; split_axis = a; }
+                }
+            }
+            if (split_axis >= 0) {
+                const int a = split_axis;
+                const float scale = B / (cmx[a] - cmn[a]);
+                auto it = std::partition(items.begin() + first, items.begin() + first + count, [&](uint32_t id) {
+                    int k = static_cast<int>((centroid(id, a) - cmn[a]) * scale);
+                    k = std::min(std::max(k, 0), B - 1);
+                    return k <= best_bin;
+                });
+                mid = static_cast<size_t>(it - items.begin());
+                if (mid == first || mid == first + count) split_axis = -1;
+            }
+        }
+        if (split_axis < 0) {  // median on the longest centroid axis (also the depth-limit path)
+            const float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
+            const int a = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);
+            mid = first + count / 2;
+            std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + first + count,
+                             [&](uint32_t x, uint32_t y) { return centroid(x, a) < centroid(y, a); });
+        }
+        const uint32_t me = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        SphereNode n;
+        bounds(first, mid - first, n.lmin, n.lmax);
+        bounds(mid, first + count - mid, n.rmin, n.rmax);
+        n.left = build(first, mid - first, depth + 1);
+        n.right = build(mid, first + count - mid, depth + 1);
+        n._pad0 = n._pad1 = 0;
+        nodes[me] = n;
+        return me;
+    }
+};
+}  // namespace
+
+bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
+    out = FastTree{};
+    if (node_count == 0 || index_len == 0) return false;
+    // ---- reference visit order (right child first, shader.wgsl:376-387) and per-slot metadata
+    out.ref_parent.assign(node_count, 0u);
+    out.slot_meta.assign(static_cast<size_t>(index_len) * 2, 0xFFFFFFFFu);
+    std::vector<uint32_t> st{0u};
+    std::vector<uint32_t> slots;
+    uint32_t rank = 0;
+    while (!st.empty()) {
+        const uint32_t ni = st.back();
+        st.pop_back();
+        const rb_bvh_node& n = ref_nodes[ni];
+        if (n.primitive_count > 0) {
+            for (uint32_t i = 0; i < n.primitive_count; ++i) {
+                const uint32_t slot = n.first_primitive + i;
+                if (slot >= index_len) continue;                     // guard :331
+                if (indices[slot] >= tri_count) { ++rank; continue; }  // guard :336
+                if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the exact walk
+                out.slot_meta[slot * 2] = ni;
+                out.slot_meta[slot * 2 + 1] = rank++;
+                slots.push_back(slot);
+            }
+        } else {
+            if (n.left < node_count) { out.ref_parent[n.left] = ni; st.push_back(n.left); }
+            if (n.right < node_count) { out.ref_parent[n.right] = ni; st.push_back(n.right); }
+        }
+    }
+    if (slots.empty() || slots.size() >= (1u << 28)) return false;
+    // ---- tight boxes per item; items are indices into `slots`
+    const size_t n = slots.size();
+    std::vector<float> bmn(n * 3), bmx(n * 3);
+    float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
+    for (size_t i = 0; i < n; ++i) {
+        const rb_gpu_triangle& t = tris[indices[slots[i]]];
+        for (int a = 0; a < 3; ++a) {
+            bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
+            bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
+            smn[a] = std::min(smn[a], bmn[i * 3 + a]);
+            smx[a] = std::max(smx[a], bmx[i * 3 + a]);
+        }
+    }
+    std::vector<uint32_t> items(n);
+    for (size_t i = 0; i < n; ++i) items[i] = static_cast<uint32_t>(i);
+    FBuilder fb{bmn, bmx, items, out.nodes, stack_limit};
+    out.root = fb.build(0, n, 1);
+    out.depth = fb.max_depth + 1;
+    out.slots.resize(n);
+    for (size_t i = 0; i < n; ++i) out.slots[i] = slots[items[i]];
+    const float dx = smx[0] - smn[0], dy = smx[1] - smn[1], dz = smx[2] - smn[2];
+    out.margin = 1e-4f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-6f;
+    return out.depth <= stack_limit;
+}
+
 }  // namespace rb

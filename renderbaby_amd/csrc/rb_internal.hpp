@@ -37,6 +37,18 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
                       std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
                       float bmax[3]);
 
+// Fast triangle tree (opt-in, rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
+struct FastTree {
+    std::vector<SphereNode> nodes;
+    std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
+    std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
+    std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
+    uint32_t root = 0x80000000u, depth = 0;
+    float margin = 0.0f;               // box inflation for the slab test
+};
+bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out);
+
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {
     C_SEGMENTS = 0, C_PATHS, C_NODES, C_TRIS, C_SPHERES, C_LIGHTS, C_MESH_HITS, C_COUNT
@@ -78,6 +90,13 @@ struct KParams {
     const uint32_t* tex_data;
     const rb_texture_info* tex_info;
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
+    const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
+    const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
+    const uint32_t* fast_slots;    // fast-leaf order -> slot
+    const uint32_t* slot_meta;     // per slot {reference leaf node, reference rank}
+    const uint32_t* ref_parent;    // reference tree parents
+    uint32_t fast_root;
+    float fast_margin;
     const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
     const float* sph_leaf;         // float4 {centre, radius} in leaf order
     const uint32_t* sph_id;        // original sphere index per leaf-order slot
@@ -115,6 +134,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream, L
                   void* ev_after_trace = nullptr);
 int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
                      uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
+int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out, void* stream);
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);
 int device_cu_count(int device);
 

@@ -331,6 +331,108 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
     }
 }
 
+// Opt-in fast walk (RB_FLAG_FAST_BVH) of the library's own SAH tree over the same triangles
+// (rb_bvh.cpp, fast_bvh_build): nearer child first, subtrees skipped when missed or entered
+// beyond the best t.  It reproduces the reference walk's winner:
+//  * candidates are evaluated with the reference's isect_triangle, so t, u, v are the same bits;
+//  * equal t resolves by the triangle's rank in the reference's visit order;
+//  * the reference only tests a triangle if every node from the root to its leaf passes
+//    intersect_aabb: an improving candidate is accepted only after that chain has been
+//    re-checked with the reference's own slab arithmetic on the reference's boxes;
+//  * boxes are inflated by a margin so rounding cannot cull a triangle the reference would hit.
+// Not a proof (an ill-conditioned Moller-Trumbore hit far outside its triangle could be missed),
+// which is why it is opt-in; the tests compare it bit for bit with the reference walk.
+template <bool STATS>
+DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    TriHit h;
+    h.hit = false;
+    h.t = 1e20f;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.slot = 0u;
+    uint32_t best_rank = 0xFFFFFFFFu;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const cf4p nodes = (cf4p)p.fast_nodes;
+    const cf4p ftris = (cf4p)p.fast_tris;
+    const cf4p rnodes = (cf4p)p.nodes;
+    const RB_CONST uint32_t* fslots = cptr(p.fast_slots);
+    const RB_CONST uint32_t* meta = cptr(p.slot_meta);
+    const RB_CONST uint32_t* parent = cptr(p.ref_parent);
+    const float m = p.fast_margin;
+
+    auto entry = [&](v4f lo, v4f hi, float& tn) -> bool {
+        const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
+        const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
+        tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+        const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+        return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
+    };
+    auto reference_would_test = [&](uint32_t leaf_node) -> bool {
+        uint32_t n = leaf_node;
+        for (;;) {
+            const v4f n0 = rnodes[n * 3u], n1 = rnodes[n * 3u + 1u];
+            if constexpr (STATS) tl.nodes++;
+            if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) return false;
+            if (n == 0u) return true;
+            n = parent[n];
+        }
+    };
+    auto leaf = [&](uint32_t ref) {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
+        for (uint32_t j = first; j < first + count; j++) {
+            const v4f a = ftris[j * 4u], b = ftris[j * 4u + 1u], c = ftris[j * 4u + 2u];
+            if constexpr (STATS) tl.tris++;
+            float u, v;
+            const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+            if (t > 0.001f && !(t > h.t)) {
+                const uint32_t slot = fslots[j];
+                const uint32_t leaf_node = meta[slot * 2u], rank = meta[slot * 2u + 1u];
+                if ((t < h.t || rank < best_rank) && reference_would_test(leaf_node)) {
+                    h.hit = true;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.slot = slot;
+                    best_rank = rank;
+                    if constexpr (STATS) tl.mesh_hits++;
+                }
+            }
+        }
+    };
+
+    uint32_t cur = p.fast_root;
+    int sp = 0;
+    for (;;) {
+        if (cur & 0x80000000u) {
+            leaf(cur);
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+            continue;
+        }
+        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        if constexpr (STATS) tl.nodes++;
+        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+        float tl_, tr_;
+        const bool hl = entry(l0, l1, tl_), hr = entry(r0, r1, tr_);
+        if (hl && hr) {
+            const bool left_first = !(tr_ < tl_);
+            stack[sp * stride] = left_first ? rref : lref;
+            sp++;
+            cur = left_first ? lref : rref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+        }
+    }
+    return h;
+}
+
 template <bool STATS>
 DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     TriHit h;
@@ -341,6 +443,7 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
     h.slot = 0u;
     const uint32_t node_count = p.u.bvh_node_count;
     if (node_count == 0u) return h;
+    if (p.fast_nodes != nullptr) return intersect_bvh_fast<STATS>(p, o, d, stack, stride, tl);
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const cf4p nodes = (cf4p)p.nodes;
     const cf4p ptris = (cf4p)p.ptris;  // 4 x float4 per triangle
@@ -1343,6 +1446,12 @@ __global__ void k_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, con
     shade[slot] = s;
 }
 
+// Copies prepared triangles into the fast tree's leaf order.
+__global__ void k_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = ptris[slots[j]];
+}
+
 // Exposes the device's /, sqrt, normalize and u32->f32 to the parity tests.
 __global__ void k_debug_math(const float* a, const float* b, float* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1421,7 +1530,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         q.queue_batch = (uint32_t)batch;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
-        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
+        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping && p.fast_nodes == nullptr;
         li.kernel_name = stepped ? "k_trace_bvh" : "k_trace";
         if (stepped) {
             if (stats)
@@ -1449,6 +1558,13 @@ int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint
     const uint32_t block = 256, grid = (index_len + block - 1) / block;
     hipLaunchKernelGGL(k_prep_tris, dim3(grid), dim3(block), 0, stream, tris, tri_count, indices, index_len, out,
                        shade);
+    return (int)hipGetLastError();
+}
+
+int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out, void* stream_) {
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), dim3(256), 0, stream, ptris, slots, n, out);
     return (int)hipGetLastError();
 }
 

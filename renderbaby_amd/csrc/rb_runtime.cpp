@@ -89,6 +89,14 @@ struct rb_engine {
     DevBuf<uint32_t> out_rgba;
     DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> queue;
+    DevBuf<rb::SphereNode> fast_nodes; // opt-in fast triangle tree (RB_FLAG_FAST_BVH)
+    DevBuf<rb::PrepTri> fast_tris;
+    DevBuf<uint32_t> fast_slots, slot_meta, ref_parent;
+    uint32_t fast_root = 0, fast_depth = 0;
+    float fast_margin = 0.0f;
+    bool fast_ready = false;
+    std::vector<rb_gpu_triangle> host_tris;  // kept only when RB_FLAG_FAST_BVH is set
+    std::vector<uint32_t> host_indices;
     DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
     DevBuf<float> sph_leaf;
     DevBuf<uint32_t> sph_id;
@@ -326,8 +334,17 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
             e->host_nodes.assign(static_cast<const rb_bvh_node*>(src), static_cast<const rb_bvh_node*>(src) + n);
             e->prep_dirty = true;
             break;
-        case 6: rc = upload(e, e->indices, src, n, &e->n_indices, true); e->prep_dirty = true; break;
-        case 7: rc = upload(e, e->tris, src, n, nullptr, true); e->n_tris = static_cast<uint32_t>(n); e->prep_dirty = true; break;
+        case 6:
+            rc = upload(e, e->indices, src, n, &e->n_indices, true);
+            e->prep_dirty = true;
+            if (e->opt.flags & RB_FLAG_FAST_BVH) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
+            break;
+        case 7:
+            rc = upload(e, e->tris, src, n, nullptr, true);
+            e->n_tris = static_cast<uint32_t>(n);
+            e->prep_dirty = true;
+            if (e->opt.flags & RB_FLAG_FAST_BVH) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
+            break;
         case 8:
             if (del) { rb_field empty{RB_UPDATE, nullptr, 0}; rc = upload_textures(e, empty); }
             else rc = upload_textures(e, f);
@@ -376,6 +393,28 @@ int ensure_prepared(rb_engine* e) {
     int rc = rb::launch_prep_tris(e->tris.ptr, e->n_tris, e->indices.ptr, len, e->ptris.ptr, e->pshade.ptr, e->stream);
     if (rc) return fail(e, RB_ERR_DEVICE, "prep kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     e->prep_dirty = false;
+    // ---- opt-in fast tree over the same triangles
+    e->fast_ready = false;
+    if ((e->opt.flags & RB_FLAG_FAST_BVH) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty()) {
+        rb::FastTree ft;
+        if (rb::fast_bvh_build(e->host_tris.data(), static_cast<uint32_t>(e->host_tris.size()), e->host_indices.data(),
+                               static_cast<uint32_t>(e->host_indices.size()), e->host_nodes.data(),
+                               static_cast<uint32_t>(e->host_nodes.size()), rb::kStackDepth, ft)) {
+            rc = upload(e, e->fast_nodes, ft.nodes.data(), ft.nodes.size(), nullptr, true);
+            if (!rc) rc = upload(e, e->fast_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
+            if (!rc) rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
+            if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
+            if (rc) return rc;
+            HIP_TRY(e, e->fast_tris.resize(ft.slots.size()));
+            rc = rb::launch_gather_tris(e->ptris.ptr, e->fast_slots.ptr, static_cast<uint32_t>(ft.slots.size()), e->fast_tris.ptr, e->stream);
+            if (rc) return fail(e, RB_ERR_DEVICE, "gather kernel launch failed");
+            HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ft` is a local
+            e->fast_root = ft.root;
+            e->fast_depth = ft.depth;
+            e->fast_margin = ft.margin;
+            e->fast_ready = true;
+        }
+    }
     return RB_OK;
 }
 
@@ -421,6 +460,14 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.stripe_rows = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     p.local_rows = e->local_rows;
     p.colors = e->colors.ptr;
+    const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
+    p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
+    p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
+    p.fast_slots = e->fast_slots.ptr;
+    p.slot_meta = e->slot_meta.ptr;
+    p.ref_parent = e->ref_parent.ptr;
+    p.fast_root = e->fast_root;
+    p.fast_margin = e->fast_margin;
     const bool use_sph_bvh = e->sph_bvh && p.u.spheres_count == e->n_spheres;
     p.sph_nodes = use_sph_bvh ? e->sph_nodes.ptr : nullptr;
     p.sph_leaf = e->sph_leaf.ptr;
@@ -433,6 +480,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     // a single-node tree is walked without a stack (rb_kernels.hip, intersect_bvh)
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
     if (use_sph_bvh) p.stack_depth = std::max(p.stack_depth, e->sph_depth);
+    if (use_fast) p.stack_depth = std::max(p.stack_depth, e->fast_depth);
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];
     p.no_leaf_stepping = e->opt._reserved[3];

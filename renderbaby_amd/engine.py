@@ -169,7 +169,7 @@ class Engine:
     """``engine_pathtracer::Engine`` for the HIP backend."""
 
     def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
-                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False):
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False):
         self._lib = load()
         cfg, keep = rc.to_c()
         opt = abi.Options()
@@ -177,7 +177,8 @@ class Engine:
         opt.shard_rank, opt.shard_count, opt.stripe_rows = shard_rank, shard_count, stripe_rows
         opt.passes_per_launch = passes_per_launch
         opt.kernel = kernel
-        opt.flags = (abi.FLAG_STATS if stats else 0) | (abi.FLAG_NO_SPHERE_BVH if no_sphere_bvh else 0)
+        opt.flags = (abi.FLAG_STATS if stats else 0) | (abi.FLAG_NO_SPHERE_BVH if no_sphere_bvh else 0) \
+            | (abi.FLAG_FAST_BVH if fast_bvh else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         self._h = self._lib.rb_create_ex(C.byref(cfg), C.byref(opt))

@@ -161,3 +161,21 @@ def test_sphere_bvh_matches_the_linear_scan(n, extent, size):
         assert st["segments"] == o_st["segments"]
     # the hit rate must be meaningful for the comparison to mean anything
     assert (o_acc[..., :3].sum(-1) > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("color_hash", [0, 1])
+@pytest.mark.parametrize("grid,w,h,spp", [(24, 64, 40, 4), (112, 96, 54, 2)])
+def test_fast_bvh_reproduces_the_reference_walk(grid, w, h, spp, color_hash):
+    # RB_FLAG_FAST_BVH: own SAH tree + culling, winner re-validated against the reference tree
+    s = scenes.mesh_scene(grid, grid, w, h, spp, 5, seed=7)
+    if color_hash:
+        u = s.uniforms.copy()
+        u["color_hash_enabled"] = 1
+        s = scenes.Scene(u, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices, s.bvh_triangles, s.uvs)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=True, fast_bvh=True)
+    bad = np.argwhere(acc.view(np.uint32) != o_acc.view(np.uint32))
+    assert len(bad) == 0, (len(bad), bad[:4])
+    assert np.array_equal(frame.pixels, o_rgba)
+    assert st["segments"] == o_st["segments"]
+    assert st["tris_tested"] < o_st["tris_tested"] / 4  # it must actually be the fast walk

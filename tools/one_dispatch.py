@@ -13,9 +13,10 @@ elif w == "c4": s = scenes.spheres_scene(1_000_000, 4096, 4096, spp, 5)
 elif w == "c4s": s = scenes.spheres_scene(1_000_000, 1024, 1024, spp, 5)
 elif w == "c5s": s = scenes.mesh_scene(1024, 512, 1920, 1080, spp, 16, seed=11, with_blob=False)
 rc = RenderConfig.from_scene(s)
-eng = Engine.new(rc, kernel=kern); eng.update(rc)
+eng = Engine.new(rc, kernel=kern, fast_bvh=bool(int(os.environ.get('RB_FAST', '0'))), stats=bool(int(os.environ.get('RB_STATS', '0')))); eng.update(rc)
 for _ in range(reps):
     eng.reset_stats(); eng.clear(); eng.dispatch(0, spp); eng.sync()
 st = eng.stats()
-print(w, spp, "kernel", kern, "ms", eng.last_dispatch_ms(), "segments", st["segments"], "Mseg/s", st["segments"] / eng.last_dispatch_ms() / 1e3)
+print(st) if os.environ.get("RB_STATS") else None
+print(w, spp, "kernel", kern, eng.last_kernel_name(), "ms", eng.last_dispatch_ms(), "segments", st["segments"], "Mseg/s", st["segments"] / eng.last_dispatch_ms() / 1e3)
 eng.close()

@@ -36,12 +36,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--stripe-rows", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.achieved = null)")
+    ap.add_argument("--fast-bvh", action="store_true", help="RB_FLAG_FAST_BVH (multi-node meshes; see DESIGN.md)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --same-device) rehearses the N>1 path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -57,9 +58,12 @@ def make_scene(name, spp):
     elif name == "c2":
         s = scenes.cornell_c2()
         desc = "C2 Cornell box (12 tris, 8 spheres, 1 area light), 1920x1080, 1024 spp, 8 bounces"
-    else:
+    elif name == "c3":
         s = scenes.mesh_c3()
         desc = "C3 procedural 50176-tri mesh + light quad, BVH leaf<=128, 1920x1080, 256 spp, 5 bounces"
+    else:
+        s = scenes.spheres_scene()
+        desc = "C4 1M random spheres over a checkerboard ground, 4096x4096, 64 spp, 5 bounces"
     if spp:
         s = s.with_params(spp=spp)
         desc += f" [spp overridden to {spp}]"
@@ -73,19 +77,30 @@ def cpu_baseline(scene, budget_s):
     from tests import _oracle
     cores = _oracle.lib().rbo_max_threads()
     h = scene.height
-    probe_rows = max(8, min(h, 64))
-    r0 = (h - probe_rows) // 2
+    # probe on a thin band first: some workloads (C4's 10^6-sphere linear scan) are far too slow
+    # on the CPU to time a whole pass
+    rows = max(1, min(h, cores // 8 if cores >= 8 else 1))
+    r0 = (h - rows) // 2
     t = time.perf_counter()
-    _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + probe_rows))
+    _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + rows))
     dt = max(time.perf_counter() - t, 1e-6)
-    per_spp_full = dt * h / probe_rows
-    n = int(max(1, min(scene.total_samples, budget_s / per_spp_full)))
-    t = time.perf_counter()
-    _, _, _, st = _oracle.render(scene, 0, n)
-    dt = time.perf_counter() - t
+    per_spp_full = dt * h / rows
+    if per_spp_full > budget_s:
+        # not even one pass fits: time as many rows of one pass as the budget allows
+        rows2 = int(max(rows, min(h, rows * budget_s / dt)))
+        r0 = (h - rows2) // 2
+        t = time.perf_counter()
+        _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + rows2))
+        dt = time.perf_counter() - t
+        sample = f"rows {r0}..{r0 + rows2} of the {scene.width}x{h} frame, 1 of {scene.total_samples} spp"
+    else:
+        n = int(max(1, min(scene.total_samples, budget_s / per_spp_full)))
+        t = time.perf_counter()
+        _, _, _, st = _oracle.render(scene, 0, n)
+        dt = time.perf_counter() - t
+        sample = f"full {scene.width}x{h} frame, {n} of {scene.total_samples} spp"
     return {"value": st["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"full {scene.width}x{scene.height} frame, {n} of {scene.total_samples} spp, "
-                      f"{st['segments']} segments in {dt:.2f} s (oracle/rb_oracle.c, OpenMP)"}
+            "sample": f"{sample}, {st['segments']} segments in {dt:.2f} s (oracle/rb_oracle.c, OpenMP)"}
 
 
 def load_traffic(workload):
@@ -143,14 +158,14 @@ def main():
     # ---- instrumented pass (untimed): work counters for the algorithmic-bytes figure
     stats = None
     if not a.no_stats:
-        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True)
+        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True, fast_bvh=a.fast_bvh)
         r.engine.reset_stats()
         r.render_local()
         stats = r.engine.stats()
         r.close()
 
     r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel,
-                        host_gather=(a.backend != "nccl"))
+                        host_gather=(a.backend != "nccl"), fast_bvh=a.fast_bvh)
     for _ in range(a.warmup):
         r.step()
     r.engine.reset_stats()

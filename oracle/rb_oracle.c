@@ -492,6 +492,13 @@ int rbo_max_threads(void) {
 int rbo_render(const rbo_scene* s, uint32_t first_pass, uint32_t n_passes,
                uint32_t row_begin, uint32_t row_end, float* accum, uint32_t* output,
                rbo_stats* stats, int n_threads) {
+    return rbo_render_window(s, first_pass, n_passes, 0u, 0xFFFFFFFFu, row_begin, row_end, accum, output, stats,
+                             n_threads);
+}
+
+int rbo_render_window(const rbo_scene* s, uint32_t first_pass, uint32_t n_passes, uint32_t col_begin,
+                      uint32_t col_end, uint32_t row_begin, uint32_t row_end, float* accum, uint32_t* output,
+                      rbo_stats* stats, int n_threads) {
     if (!s || !accum || !output) return -1;
     const rb_uniforms* un = &s->uniforms;
     if (row_end > un->height) row_end = un->height;
@@ -511,7 +518,7 @@ int rbo_render(const rbo_scene* s, uint32_t first_pass, uint32_t n_passes,
 #pragma omp for schedule(dynamic, 1)
         for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; yy++) {
             uint32_t y = (uint32_t)yy;
-            for (uint32_t x = 0; x < width; x++) {
+            for (uint32_t x = col_begin; x < (col_end < width ? col_end : width); x++) {
                 uint32_t pixel_index = y * width + x;
                 float* acc = accum + (size_t)pixel_index * 4u;
                 v3 accumulated = V(acc[0], acc[1], acc[2]);

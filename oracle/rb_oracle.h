@@ -94,6 +94,11 @@ int rbo_render(const rbo_scene* s, uint32_t first_pass, uint32_t n_passes,
                uint32_t row_begin, uint32_t row_end, float* accum, uint32_t* output,
                rbo_stats* stats, int n_threads);
 
+/* Same, restricted to columns [col_begin, col_end) as well (for bounded CPU-baseline samples). */
+int rbo_render_window(const rbo_scene* s, uint32_t first_pass, uint32_t n_passes, uint32_t col_begin,
+                      uint32_t col_end, uint32_t row_begin, uint32_t row_end, float* accum, uint32_t* output,
+                      rbo_stats* stats, int n_threads);
+
 /* gpu_wrapper.rs:432-463: packed u32 (shader order) -> RGBA8 with x reversed, A=255 */
 void rbo_read_pixels(const uint32_t* output, uint32_t width, uint32_t height, uint8_t* rgba);
 

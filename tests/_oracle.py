@@ -66,6 +66,9 @@ def lib():
         L.rbo_render.restype = C.c_int
         L.rbo_render.argtypes = [C.POINTER(Scene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.rbo_render_window.restype = C.c_int
+        L.rbo_render_window.argtypes = [C.POINTER(Scene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]
         L.rbo_bvh_build.restype = C.c_int
         L.rbo_bvh_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
         L.rbo_max_threads.restype = C.c_int
@@ -124,7 +127,7 @@ class OracleScene:
         self.c = s
 
 
-def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0, samples_per_pass=1):
+def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0, samples_per_pass=1, cols=None):
     """Returns (accum[h,w,4] f32, output[h,w] u32 packed shader order, rgba[h,w,4] mirrored, stats dict)."""
     L = lib()
     os_ = OracleScene(scene, samples_per_pass)
@@ -138,8 +141,9 @@ def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0,
     output = np.zeros((h, w), dtype=np.uint32)
     st = Stats()
     r0, r1 = rows if rows else (0, h)
-    rc = L.rbo_render(C.byref(os_.c), first_pass, n_passes, r0, r1, accum.ctypes.data, output.ctypes.data,
-                      C.byref(st), threads)
+    c0, c1 = cols if cols else (0, w)
+    rc = L.rbo_render_window(C.byref(os_.c), first_pass, n_passes, c0, c1, r0, r1, accum.ctypes.data,
+                             output.ctypes.data, C.byref(st), threads)
     assert rc == 0, rc
     rgba = np.zeros((h, w, 4), dtype=np.uint8)
     L.rbo_read_pixels(output.ctypes.data, w, h, rgba.ctypes.data)

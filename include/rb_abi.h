@@ -353,6 +353,14 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
  * dot on n input pairs (out8n: 8*n floats) so tests can check them against
  * IEEE-754 results computed on the host. */
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
+/* Test hook: checks the kernels' fast exact reciprocal against the compiler's correctly rounded
+ * 1/b for all 2^23 significands (both signs) at one biased exponent; out16[0] = mismatch count. */
+int rb_debug_rcp_exhaustive(uint32_t biased_exponent, uint32_t* out16);
+/* Test hook: the same for the fast exact division a/b over a block of significand pairs
+ * (denominators [b_begin, +b_count) x numerators [a_begin, +a_count), biased exponents ea, eb);
+ * out16[0] = mismatch count, then up to 7 (a, b) bit patterns. */
+int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,
+                            uint32_t a_count, unsigned long long* out16);
 
 /* Name of the render kernel the most recent rb_dispatch used ("k_trace", "k_trace_bvh",
  * "k_queue", "k_pixel"). */

@@ -61,7 +61,119 @@ DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 DEV f3 divs(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
 DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV f3 normalize(f3 a) { return divs(a, sqrtf(dot(a, a))); }
+DEV f3 div3_exact(f3 a, float b);
+DEV float sqrt_exact(float x);
+DEV f3 normalize(f3 a) { return div3_exact(a, sqrt_exact(dot(a, a))); }
+
+// ---- IEEE-exact 1/b in 3-5 instructions instead of the 12-instruction a/b expansion.
+// v_rcp_f32 is accurate to 1 ulp; one (RB_RCP_STEPS=1) or two Newton steps with FMA give the
+// correctly rounded reciprocal for every significand except a few (e.g. all ones), which is a
+// property of the significand alone as long as b and 1/b are normal.  Lanes outside
+// [2^-100, 2^100] or with a significand the exhaustive device check (rb_debug_rcp_exhaustive,
+// tests/test_gpu_parity.py::test_fast_reciprocal_is_exhaustively_exact) has not cleared fall back
+// to the compiler's division, so the result is `1.0f / b` bit for bit in every case.
+#ifndef RB_RCP_STEPS
+#define RB_RCP_STEPS 1
+#endif
+#ifndef RB_FAST_RCP
+#define RB_FAST_RCP 1
+#endif
+DEV float rcp_newton(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+#if RB_RCP_STEPS >= 2
+    e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+#endif
+    return r;
+}
+DEV bool rcp_safe(float b) {
+    const uint32_t x = __float_as_uint(b) & 0x7FFFFFFFu;
+    // 2^-100 <= |b| < 2^100 and significand not all ones
+    return (x - 0x0D800000u) < 0x64000000u && (x & 0x007FFFFFu) != 0x007FFFFFu;
+}
+DEV float rcp_exact(float b) {
+#if RB_FAST_RCP
+    if (rcp_safe(b)) return rcp_newton(b);
+#endif
+    return 1.0f / b;
+}
+
+// ---- IEEE-exact a/b from the exact reciprocal: q0 = RN(a*y), r = a - b*q0 (exact in an FMA),
+// q = RN(q0 + r*y) with y = RN(1/b).  Whether q is the correctly rounded quotient depends only on
+// the two significands while a, b, a/b and r stay clear of the subnormal range; the device check
+// rb_debug_div_exhaustive walked ALL 2^23 x 2^23 significand pairs with zero mismatches
+// (profiles/r01_div_exhaustive_2p46.log; sampled again by the test suite).  Used where one
+// denominator serves three numerators (normalize), so the range checks amortise; anything
+// outside the checked ranges takes the compiler's division, so results never change.
+#ifndef RB_FAST_DIV
+#define RB_FAST_DIV 1
+#endif
+DEV float div_newton(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, y, q0);
+}
+// b in [2^-60, 2^60), significand not all ones
+DEV bool div_safe_den(float b) {
+    const uint32_t x = __float_as_uint(b) & 0x7FFFFFFFu;
+    return (x - 0x21800000u) < 0x3C000000u && (x & 0x007FFFFFu) != 0x007FFFFFu;
+}
+// v / len for len = sqrt(dot(v, v)) (normalize).  len < 2^59 bounds every |component| below 2^60
+// (anything larger would have made len infinite); a non-zero component must be >= 2^-100 in
+// magnitude so that q0 and the exact remainder stay representable.  A zero numerator keeps its
+// sign through the final copysign, which is also the sign of every non-zero quotient (len > 0).
+DEV f3 div3_exact(f3 a, float b) {
+#if RB_FAST_DIV
+    // (x << 1) - 2 wraps a zero to 0xFFFFFFFE, so the unsigned minimum flags only 0 < |x| < 2^-100
+    const uint32_t tx = (__float_as_uint(a.x) << 1) - 2u, ty = (__float_as_uint(a.y) << 1) - 2u,
+                   tz = (__float_as_uint(a.z) << 1) - 2u;
+    const bool num_ok = min(min(tx, ty), tz) >= (0x0D800000u << 1) - 2u;
+    const uint32_t xb = __float_as_uint(b);  // b >= 0: sign bit clear unless -0 / NaN payloads
+    const bool den_ok = (xb - 0x21800000u) < 0x3B800000u && (xb & 0x007FFFFFu) != 0x007FFFFFu;  // [2^-60, 2^59)
+    if (num_ok && den_ok) {
+        const float y = rcp_newton(b);
+        const float qx = div_newton(a.x, b, y), qy = div_newton(a.y, b, y), qz = div_newton(a.z, b, y);
+        return mk(__builtin_copysignf(qx, a.x), __builtin_copysignf(qy, a.y), __builtin_copysignf(qz, a.z));
+    }
+#endif
+    return mk(a.x / b, a.y / b, a.z / b);
+}
+// ---- IEEE-exact sqrt without the subnormal / zero / infinity handling of the compiler's
+// expansion: v_sqrt_f32 (1 ulp), then pick among s-1ulp, s, s+1ulp by the sign of the exact
+// residuals x - s_lo*s and x - s_hi*s (the same selection the compiler emits).  Valid for
+// x in [2^-60, 2^60); checked for all 2^23 significands at an even and an odd exponent by
+// rb_debug_rcp_exhaustive (mode 1).  Everything else takes sqrtf.
+#ifndef RB_FAST_SQRT
+#define RB_FAST_SQRT 1
+#endif
+DEV float sqrt_newton(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_lo = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_lo = __builtin_fmaf(-s_lo, s, x);
+    const float r_hi = __builtin_fmaf(-s_hi, s, x);
+    float out = (r_lo <= 0.0f) ? s_lo : s;
+    out = (r_hi > 0.0f) ? s_hi : out;
+    return out;
+}
+DEV float sqrt_exact(float x) {
+#if RB_FAST_SQRT
+    if ((__float_as_uint(x) - 0x21800000u) < 0x3C000000u) return sqrt_newton(x);  // positive, [2^-60, 2^60)
+#endif
+    return sqrtf(x);
+}
+
+// 1/a for the triangle test: the reference rejects |a| < 1e-6 first (its reciprocal is never used),
+// so only the upper range and the significand need checking.
+DEV float rcp_tri(float a) {
+#if RB_FAST_RCP
+    const uint32_t x = __float_as_uint(a) & 0x7FFFFFFFu;
+    if (x < 0x71800000u && (x & 0x007FFFFFu) != 0x007FFFFFu) return rcp_newton(a);
+#endif
+    return 1.0f / a;
+}
 
 // WGSL u32(f32) / i32(f32): truncate + saturate, NaN -> 0
 DEV uint32_t f2u(float f) {
@@ -170,7 +282,7 @@ DEV float isect_triangle(f3 o, f3 d, f3 v0, f3 edge1, f3 edge2, float& uo, float
 #if RB_TRI_BRANCHFREE
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);
-    const float f = 1.0f / a;
+    const float f = rcp_tri(a);
     const f3 s = o - v0;
     const float u = f * dot(s, h);
     const f3 q = cross(s, edge1);
@@ -184,7 +296,7 @@ DEV float isect_triangle(f3 o, f3 d, f3 v0, f3 edge1, f3 edge2, float& uo, float
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);
     if (fabsf(a) < 1e-6f) return -1.0f;
-    const float f = 1.0f / a;
+    const float f = rcp_tri(a);
     const f3 s = o - v0;
     const float u = f * dot(s, h);
     if (u < 0.0f || u > 1.0f) return -1.0f;
@@ -299,7 +411,7 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
     const f2 hy = d.z * e2x - d.x * e2z;
     const f2 hz = d.x * e2y - d.y * e2x;
     const f2 a = (e1x * hx + e1y * hy) + e1z * hz;
-    const f2 f = {1.0f / a.x, 1.0f / a.y};
+    const f2 f = {rcp_tri(a.x), rcp_tri(a.y)};
     const f2 sx = o.x - v0x, sy = o.y - v0y, sz = o.z - v0z;
     const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
     // q = cross(s, edge1)
@@ -351,7 +463,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
     h.v = 0.0f;
     h.slot = 0u;
     uint32_t best_rank = 0xFFFFFFFFu;
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
     const cf4p nodes = (cf4p)p.fast_nodes;
     const cf4p ftris = (cf4p)p.fast_tris;
     const cf4p rnodes = (cf4p)p.nodes;
@@ -444,7 +556,7 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
     const uint32_t node_count = p.u.bvh_node_count;
     if (node_count == 0u) return h;
     if (p.fast_nodes != nullptr) return intersect_bvh_fast<STATS>(p, o, d, stack, stride, tl);
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
     const cf4p nodes = (cf4p)p.nodes;
     const cf4p ptris = (cf4p)p.ptris;  // 4 x float4 per triangle
 
@@ -597,7 +709,7 @@ DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& clo
     const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
     const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
     const float m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
     float best = closest_t;
     uint32_t best_id = 0xFFFFFFFFu;
 
@@ -1314,7 +1426,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_bvh(const KParams p) {
             th.t = 1e20f;
             th.u = th.v = 0.0f;
             th.slot = 0u;
-            inv = mk(1.0f / pt.d.x, 1.0f / pt.d.y, 1.0f / pt.d.z);
+            inv = mk(rcp_exact(pt.d.x), rcp_exact(pt.d.y), rcp_exact(pt.d.z));
             stack[0] = 0u;
             sp = 1;
             state = TRAV;
@@ -1452,6 +1564,61 @@ __global__ void k_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint3
     if (j < n) out[j] = ptris[slots[j]];
 }
 
+// Exhaustive check of rcp_newton against the compiler's correctly rounded 1/b: every one of the
+// 2^23 significands at biased exponent `expo`, both signs.  mismatch[0] counts differing results
+// among rcp_safe inputs; mismatch[1..] records up to 15 offending bit patterns.
+__global__ void k_rcp_exhaustive(uint32_t expo, uint32_t* mismatch) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (1u << 23)) return;
+    for (uint32_t sign = 0; sign < 2; sign++) {
+        const uint32_t bits = (sign << 31) | ((expo & 0xFFu) << 23) | m;
+        const float b = __uint_as_float(bits);
+        float want, got;
+        if (expo & 0x100u) {  // mode 1: sqrt (positive operands only)
+            if (sign) continue;
+            want = sqrtf(b);
+            got = sqrt_exact(b);
+        } else {
+            if (!rcp_safe(b)) continue;
+            want = 1.0f / b;
+            got = rcp_newton(b);
+        }
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            const uint32_t k = atomicAdd(&mismatch[0], 1u);
+            if (k < 15u) mismatch[1u + k] = bits;
+        }
+    }
+}
+
+// Exhaustive check of div_newton: thread = one denominator significand (biased exponent eb),
+// loop over `a_count` numerator significands starting at a_begin (biased exponent ea).
+__global__ void k_div_exhaustive(uint32_t b_begin, uint32_t ea, uint32_t eb, uint32_t a_begin, uint32_t a_count,
+                                 unsigned long long* mismatch) {
+    const uint32_t mb = b_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (mb >= (1u << 23)) return;
+    const float b = __uint_as_float((eb << 23) | mb);
+    if (!div_safe_den(b)) return;
+    const float y = rcp_newton(b);
+    unsigned long long bad = 0;
+    uint32_t first_bad = 0;
+    for (uint32_t i = 0; i < a_count; i++) {
+        const float a = __uint_as_float((ea << 23) | ((a_begin + i) & 0x7FFFFFu));
+        const float want = a / b;
+        const float got = div_newton(a, b, y);
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            if (bad == 0) first_bad = __float_as_uint(a);
+            bad++;
+        }
+    }
+    if (bad) {
+        const unsigned long long k = atomicAdd(&mismatch[0], bad);
+        if (k < 7ull) {
+            mismatch[1 + 2 * k] = first_bad;
+            mismatch[2 + 2 * k] = __float_as_uint(b);
+        }
+    }
+}
+
 // Exposes the device's /, sqrt, normalize and u32->f32 to the parity tests.
 __global__ void k_debug_math(const float* a, const float* b, float* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1565,6 +1732,20 @@ int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, 
     if (n == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), dim3(256), 0, stream, ptris, slots, n, out);
+    return (int)hipGetLastError();
+}
+
+int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,
+                          uint32_t a_count, unsigned long long* mismatch, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_div_exhaustive, dim3((b_count + 255) / 256), dim3(256), 0, stream, b_begin, ea, eb, a_begin,
+                       a_count, mismatch);
+    return (int)hipGetLastError();
+}
+
+int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_rcp_exhaustive, dim3((1u << 23) / 256), dim3(256), 0, stream, expo, mismatch);
     return (int)hipGetLastError();
 }
 

@@ -960,6 +960,36 @@ int rb_device_name(int device, char* buf, size_t buf_len) {
     return RB_OK;
 }
 
+// Test hook: exhaustive device check of the fast reciprocal (all 2^23 significands, both signs)
+// at one biased exponent.  out16[0] = number of mismatches, out16[1..15] = offending bit patterns.
+int rb_debug_rcp_exhaustive(uint32_t biased_exponent, uint32_t* out16) {
+    if (!out16) return RB_ERR_NULL_ARGUMENT;
+    uint32_t* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), 64) != hipSuccess) return RB_ERR_DEVICE;
+    (void)hipMemset(d, 0, 64);
+    int rc = rb::launch_rcp_exhaustive(biased_exponent, d, nullptr);
+    hipError_t st = hipDeviceSynchronize();
+    (void)hipMemcpy(out16, d, 64, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return (rc || st != hipSuccess) ? RB_ERR_DEVICE : RB_OK;
+}
+
+// Test hook: device check of the fast exact division over denominators [b_begin, b_begin+b_count)
+// x numerators [a_begin, a_begin+a_count) (significands; biased exponents ea / eb).
+// out16[0] = mismatch count, then up to 7 (a, b) bit-pattern pairs.
+int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,
+                            uint32_t a_count, unsigned long long* out16) {
+    if (!out16) return RB_ERR_NULL_ARGUMENT;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), 128) != hipSuccess) return RB_ERR_DEVICE;
+    (void)hipMemset(d, 0, 128);
+    int rc = rb::launch_div_exhaustive(b_begin, b_count, ea, eb, a_begin, a_count, d, nullptr);
+    hipError_t st = hipDeviceSynchronize();
+    (void)hipMemcpy(out16, d, 128, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return (rc || st != hipSuccess) ? RB_ERR_DEVICE : RB_OK;
+}
+
 // Debug hook for tests/test_gpu_math.py: device /, sqrt, normalize, u32->f32, min/max, dot.
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n) {
     if (!a || !b || !out8n) return RB_ERR_NULL_ARGUMENT;

@@ -179,3 +179,31 @@ def test_fast_bvh_reproduces_the_reference_walk(grid, w, h, spp, color_hash):
     assert np.array_equal(frame.pixels, o_rgba)
     assert st["segments"] == o_st["segments"]
     assert st["tris_tested"] < o_st["tris_tested"] / 4  # it must actually be the fast walk
+
+
+def test_fast_reciprocal_and_sqrt_are_exhaustively_exact():
+    # the kernels replace the 12-instruction IEEE divide by rcp + Newton/FMA steps where the
+    # operands allow; correctness is a property of the significand, so it is checked for ALL
+    # 2^23 significands (both signs) at exponents across the admitted range
+    from renderbaby_amd._lib import load
+    lib = load()
+    for expo in (27, 28, 67, 126, 127, 128, 187, 226):
+        out = np.zeros(16, np.uint32)
+        assert lib.rb_debug_rcp_exhaustive(expo, out.ctypes.data) == 0
+        assert out[0] == 0, (expo, [hex(int(x)) for x in out[1:4]])
+    for expo in (67, 68, 126, 127, 128, 186, 0, 1, 254):  # sqrt: even/odd exponents + fallback ranges
+        out = np.zeros(16, np.uint32)
+        assert lib.rb_debug_rcp_exhaustive(0x100 | expo, out.ctypes.data) == 0
+        assert out[0] == 0, ("sqrt", expo, [hex(int(x)) for x in out[1:4]])
+
+
+def test_fast_division_on_sampled_significand_pairs():
+    # the full 2^46-pair walk takes 67 s (profiles/r01_div_exhaustive_2p46.log: 0 mismatches);
+    # here: 2^12 denominators x 2^23 numerators for several exponent pairs
+    from renderbaby_amd._lib import load
+    lib = load()
+    for ea, eb, b0 in ((127, 127, 0x123000), (90, 150, 0x7FF000), (160, 100, 0x000000), (127, 68, 0x400000),
+                       (30, 127, 0x2AB000)):
+        out = np.zeros(16, np.uint64)
+        assert lib.rb_debug_div_exhaustive(b0, 1 << 12, ea, eb, 0, 1 << 23, out.ctypes.data) == 0
+        assert out[0] == 0, (ea, eb, [hex(int(x)) for x in out[1:5]])

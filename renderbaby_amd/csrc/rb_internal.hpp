@@ -134,6 +134,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream, L
                   void* ev_after_trace = nullptr);
 int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices,
                      uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
+int launch_prep_materials(void* first_material, uint32_t stride, uint32_t n, void* stream);
 int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out, void* stream);
 int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,
                           uint32_t a_count, unsigned long long* mismatch16, void* stream);

@@ -652,7 +652,8 @@ DEV void tri_uv(const KParams& p, const TriHit& h, float& uvx, float& uvy) {
 // ------------------------------------------------------------- materials --
 struct Mat {
     f3 diffuse, specular, emissive;
-    float shininess;
+    float fuzz;     // clamp(1 - shininess / 1000, 0, 1)   (shader.wgsl:637)
+    bool metal;     // mean(specular) > 0.01 && mean(diffuse) < 0.01   (:615-623)
     int32_t tex;
 };
 DEV Mat load_mat(const rb_material* m) {
@@ -662,9 +663,10 @@ DEV Mat load_mat(const rb_material* m) {
     Mat r;
     r.diffuse = mk(d.x, d.y, d.z);
     r.specular = mk(s.x, s.y, s.z);
-    r.shininess = s.w;
+    r.fuzz = d.w;          // device copy's _pad1, filled by k_prep_materials
     r.emissive = mk(e.x, e.y, e.z);
     r.tex = (int32_t)t.z;
+    r.metal = t.w != 0u;   // device copy's _pad2
     return r;
 }
 DEV int32_t load_tex_index(const rb_material* m) {
@@ -920,7 +922,8 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
     m.diffuse = mk(0, 0, 0);
     m.specular = mk(0, 0, 0);
     m.emissive = mk(0, 0, 0);
-    m.shininess = 0.0f;
+    m.fuzz = 1.0f;
+    m.metal = false;  // ground (diffuse 0.5) and colour-hash triangles (specular 0) are never metal
     m.tex = -1;
     if (tri_won_a) {
         // the BVH hit replaced closest_hit, including uv and use_texture, even if a
@@ -968,9 +971,9 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
         }
     }
 
-    const float specular_strength = (m.specular.x + m.specular.y + m.specular.z) / 3.0f;
-    const float diffuse_strength = (m.diffuse.x + m.diffuse.y + m.diffuse.z) / 3.0f;
-    const bool is_metal = specular_strength > 0.01f && diffuse_strength < 0.01f;
+    // is_metal / fuzz (:615-623,637) are pure functions of the material: evaluated once per
+    // material at upload (k_prep_materials) with the shader's arithmetic
+    const bool is_metal = m.metal;
 
     pt.color = pt.color + pt.att * m.emissive;  // :626
 
@@ -984,7 +987,7 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
 #endif
     f3 scattered, albedo;
     if (is_metal) {
-        const float fuzz = fminf(fmaxf(1.0f - (m.shininess / 1000.0f), 0.0f), 1.0f);
+        const float fuzz = m.fuzz;
         const f3 reflected = reflect_vector(normalize(d), normal);
         scattered = reflected + fuzz * random_unit_vector(pt.seed);
         if (dot(scattered, normal) <= 0.0f) return false;
@@ -1558,6 +1561,20 @@ __global__ void k_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, con
     shade[slot] = s;
 }
 
+// Per-material invariants of the shading branch (shader.wgsl:615-623,637), written into the pad
+// words of the DEVICE copy of each Material (the caller's buffers are never touched).
+__global__ void k_prep_materials(unsigned char* first_material, uint32_t stride, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rb_material* m = reinterpret_cast<rb_material*>(first_material + (size_t)i * stride);
+    const float specular_strength = (m->specular[0] + m->specular[1] + m->specular[2]) / 3.0f;
+    const float diffuse_strength = (m->diffuse[0] + m->diffuse[1] + m->diffuse[2]) / 3.0f;
+    const bool is_metal = specular_strength > 0.01f && diffuse_strength < 0.01f;
+    const float fuzz = fminf(fmaxf(1.0f - (m->shininess / 1000.0f), 0.0f), 1.0f);
+    m->_pad1 = fuzz;
+    m->_pad2 = is_metal ? 1u : 0u;
+}
+
 // Copies prepared triangles into the fast tree's leaf order.
 __global__ void k_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1725,6 +1742,14 @@ int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint
     const uint32_t block = 256, grid = (index_len + block - 1) / block;
     hipLaunchKernelGGL(k_prep_tris, dim3(grid), dim3(block), 0, stream, tris, tri_count, indices, index_len, out,
                        shade);
+    return (int)hipGetLastError();
+}
+
+int launch_prep_materials(void* first_material, uint32_t stride, uint32_t n, void* stream_) {
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_prep_materials, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       static_cast<unsigned char*>(first_material), stride, n);
     return (int)hipGetLastError();
 }
 

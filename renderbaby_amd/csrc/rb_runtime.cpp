@@ -273,6 +273,13 @@ int upload_textures(rb_engine* e, const rb_field& f) {
     return RB_OK;
 }
 
+int prep_materials(rb_engine* e, rb_material* first, size_t stride, size_t n) {
+    if (!first || n == 0) return RB_OK;
+    int rc = rb::launch_prep_materials(first, static_cast<uint32_t>(stride), static_cast<uint32_t>(n), e->stream);
+    if (rc) return fail(e, RB_ERR_DEVICE, "material prep launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    return RB_OK;
+}
+
 // Spheres beyond kSphereBvhThreshold get the library's own acceleration structure; the
 // reference's linear scan (shader.wgsl:574-586) stays the rule for small counts.
 int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
@@ -319,14 +326,20 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
         case 1:
             rc = upload(e, e->spheres, src, n, nullptr, true);
             e->n_spheres = static_cast<uint32_t>(n);
+            if (!rc) rc = prep_materials(e, e->spheres.ptr ? &e->spheres.ptr->material : nullptr, sizeof(rb_sphere), n);
             if (!rc) rc = build_sphere_bvh(e, static_cast<const rb_sphere*>(src), n);
             break;
         case 2: rc = upload(e, e->uvs, src, n, nullptr, true); e->n_uvs = static_cast<uint32_t>(n); break;
-        case 3: rc = upload(e, e->meshes, src, n, nullptr, true); e->n_meshes = static_cast<uint32_t>(n); break;
+        case 3:
+            rc = upload(e, e->meshes, src, n, nullptr, true);
+            e->n_meshes = static_cast<uint32_t>(n);
+            if (!rc) rc = prep_materials(e, e->meshes.ptr ? &e->meshes.ptr->material : nullptr, sizeof(rb_mesh), n);
+            break;
         case 4:
             // delete_lights creates a 4-byte buffer (buffers.rs:389-391): arrayLength() == 0
             rc = upload(e, e->lights, src, n, &e->n_lights, !del);
             if (del) e->n_lights = 0;
+            if (!rc) rc = prep_materials(e, e->lights.ptr ? &e->lights.ptr->material : nullptr, sizeof(rb_point_light), e->n_lights);
             break;
         case 5:
             rc = upload(e, e->nodes, src, n, nullptr, true);

@@ -77,30 +77,37 @@ def cpu_baseline(scene, budget_s):
     from tests import _oracle
     cores = _oracle.lib().rbo_max_threads()
     h, w = scene.height, scene.width
-    # probe on a small window first: some workloads (C4's 10^6-sphere linear scan) are far too
-    # slow on the CPU to time a whole pass
+    # Grow a centred window of ONE pass until it takes long enough to time (some workloads, e.g.
+    # C4's 10^6-sphere linear scan, cannot afford a whole pass); then either extend to several
+    # full passes or stop at the largest window that fits the budget.
     ph, pw = min(h, max(1, cores // 4)), min(w, 32)
-    r0, c0 = (h - ph) // 2, (w - pw) // 2
-    t = time.perf_counter()
-    _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + ph), cols=(c0, c0 + pw))
-    dt = max(time.perf_counter() - t, 1e-6)
-    per_spp_full = dt * (h * w) / (ph * pw)
-    if per_spp_full > budget_s:
-        # not even one pass fits: time a centred window of one pass sized to the budget
-        scale = min(budget_s / dt, (h * w) / (ph * pw))
-        ph2 = int(max(ph, min(h, ph * scale ** 0.5)))
-        pw2 = int(max(pw, min(w, pw * scale ** 0.5)))
-        r0, c0 = (h - ph2) // 2, (w - pw2) // 2
+    while True:
+        r0, c0 = (h - ph) // 2, (w - pw) // 2
         t = time.perf_counter()
-        _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + ph2), cols=(c0, c0 + pw2))
-        dt = time.perf_counter() - t
-        sample = f"window {pw2}x{ph2} at the centre of the {w}x{h} frame, 1 of {scene.total_samples} spp"
-    else:
-        n = int(max(1, min(scene.total_samples, budget_s / per_spp_full)))
+        _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + ph), cols=(c0, c0 + pw))
+        dt = max(time.perf_counter() - t, 1e-6)
+        full = (ph == h and pw == w)
+        if full or dt >= 0.5:
+            break
+        grow = min(8.0, max(2.0, 0.75 / dt))
+        ph, pw = min(h, int(ph * grow ** 0.5) + 1), min(w, int(pw * grow ** 0.5) + 1)
+    per_pass = dt * (h * w) / (ph * pw)
+    if per_pass <= budget_s:
+        n = int(max(1, min(scene.total_samples, budget_s / per_pass)))
         t = time.perf_counter()
         _, _, _, st = _oracle.render(scene, 0, n)
         dt = time.perf_counter() - t
         sample = f"full {w}x{h} frame, {n} of {scene.total_samples} spp"
+    else:
+        scale = max(1.0, min(budget_s / dt, (h * w) / (ph * pw)))
+        ph2, pw2 = min(h, int(ph * scale ** 0.5)), min(w, int(pw * scale ** 0.5))
+        if ph2 * pw2 > ph * pw * 1.5:
+            r0, c0 = (h - ph2) // 2, (w - pw2) // 2
+            t = time.perf_counter()
+            _, _, _, st = _oracle.render(scene, 0, 1, rows=(r0, r0 + ph2), cols=(c0, c0 + pw2))
+            dt = time.perf_counter() - t
+            ph, pw = ph2, pw2
+        sample = f"window {pw}x{ph} at the centre of the {w}x{h} frame, 1 of {scene.total_samples} spp"
     return {"value": st["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{sample}, {st['segments']} segments in {dt:.2f} s (oracle/rb_oracle.c, OpenMP)"}
 

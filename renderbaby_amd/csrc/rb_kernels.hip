@@ -985,15 +985,19 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
         asm volatile("" ::"v"(r2.x), "v"(r2.y), "v"(r2.z));
     }
 #endif
+    // Both scatter branches draw exactly one random unit vector (:472, :488) and nothing else
+    // touches the seed, so the rejection loop runs once for the whole wavefront instead of once
+    // per branch; likewise the final normalize below is shared.
+    const f3 ruv = random_unit_vector(pt.seed);
     f3 scattered, albedo;
+    bool absorbed = false;
     if (is_metal) {
-        const float fuzz = m.fuzz;
         const f3 reflected = reflect_vector(normalize(d), normal);
-        scattered = reflected + fuzz * random_unit_vector(pt.seed);
-        if (dot(scattered, normal) <= 0.0f) return false;
+        scattered = reflected + m.fuzz * ruv;
+        absorbed = dot(scattered, normal) <= 0.0f;  // :640-642
         albedo = m.specular;
     } else {
-        const f3 sd = normal + random_unit_vector(pt.seed);
+        const f3 sd = normal + ruv;
         scattered = near_zero(sd) ? normal : normalize(sd);
         albedo = m.diffuse;
         if (use_tex) {
@@ -1001,6 +1005,7 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
             albedo = albedo * sample_texture(p, m.tex, uvx, uvy);
         }
     }
+    if (absorbed) return false;
     pt.att = pt.att * albedo;
     pt.o = pos + 0.001f * normal;
     pt.d = normalize(scattered);

@@ -573,20 +573,20 @@ DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t
         if (first < end && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
 #if RB_TRI_PAIRS
             uint32_t slot = first;
-            for (; slot + 2u <= end; slot += 2u) {
-                const v4f a0 = ptris[slot * 4u], b0 = ptris[slot * 4u + 1u], c0 = ptris[slot * 4u + 2u];
-                const v4f a1 = ptris[slot * 4u + 4u], b1 = ptris[slot * 4u + 5u], c1 = ptris[slot * 4u + 6u];
+            cf4p tp = ptris + (size_t)first * 4u;  // running pointer: one scalar add per step, immediate offsets
+            for (; slot + 2u <= end; slot += 2u, tp += 8) {
+                const v4f a0 = tp[0], b0 = tp[1], c0 = tp[2];
+                const v4f a1 = tp[4], b1 = tp[5], c1 = tp[6];
                 const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
                 if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
-                const float before = h.t;
                 test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, o, d, h, tl);
-                (void)before;
             }
-            for (; slot < end; slot++) {
+            for (; slot < end; slot++, tp += 4) {
+                const v4f a = tp[0], b = tp[1], c = tp[2];
 #else
             for (uint32_t slot = first; slot < end; slot++) {
-#endif
                 const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+#endif
                 if (__float_as_uint(c.w) != 0u) {  // guard :336
                     if constexpr (STATS) tl.tris++;
                     const float before = h.t;
@@ -829,8 +829,9 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
     for (uint32_t base = 0; base < ns; base += 32u) {
         const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
         uint32_t cand = 0u;
-        for (uint32_t k = 0; k < n; k++) {
-            const v4f cr = sph4[(base + k) * 6u];
+        cf4p sp_ = sph4 + (size_t)base * 6u;
+        for (uint32_t k = 0; k < n; k++, sp_ += 6) {
+            const v4f cr = sp_[0];
             if constexpr (STATS) tl.spheres++;
             const f3 oc = o - mk(cr.x, cr.y, cr.z);
             const float half_b = dot(oc, d);

@@ -207,3 +207,40 @@ def test_fast_division_on_sampled_significand_pairs():
         out = np.zeros(16, np.uint64)
         assert lib.rb_debug_div_exhaustive(b0, 1 << 12, ea, eb, 0, 1 << 23, out.ctypes.data) == 0
         assert out[0] == 0, (ea, eb, [hex(int(x)) for x in out[1:5]])
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 5), (5, 1), (2, 2), (17, 3)])
+def test_degenerate_frame_sizes(w, h):
+    # width-1 / height-1 divisors of the primary ray become 0 for one-pixel axes (shader.wgsl:699-700):
+    # inf/NaN directions must flow through exactly as in the oracle (every test fails => sky)
+    s = scenes.feature_scene(w, h, 3, 4)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    for kernel in KERNELS:
+        frame, acc, st = _hip(s, kernel)
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (kernel, acc, o_acc)
+        assert np.array_equal(frame.pixels, o_rgba)
+        assert st["segments"] == o_st["segments"]
+
+
+def test_zero_samples_and_zero_depth():
+    s = scenes.cornell(8, 4, 0, 4)  # total_samples = 0: no passes; the reference returns the cleared buffers
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc)
+    f = eng.render(rc)
+    assert np.all(f.pixels == 0)
+    it = eng.frame_iterator(RenderConfig.from_scene(s, create=False))
+    assert not it.has_next()
+    eng.close()
+    s = scenes.cornell(8, 4, 2, 0)  # max_depth = 0: every path is black
+    frame, acc, st = _hip(s, abi.KERNEL_STREAM)
+    assert np.all(frame.pixels[..., :3] == 0) and np.all(frame.pixels[..., 3] == 255)
+    assert st["segments"] == 0 and st["paths"] == 8 * 4 * 2
+
+
+def test_largest_frame_of_the_baseline_configs():
+    # 4096 x 4096 (C4's frame): addressing of a 16.8 M-pixel frame, sky only, 1 spp
+    s = scenes.sky_only(4096, 4096, 1)
+    frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=False)
+    assert frame.pixels.shape == (4096, 4096, 4)
+    assert np.all(frame.pixels.reshape(-1, 4) == np.array([147, 164, 181, 255], dtype=np.uint8))
+    assert st["paths"] == 4096 * 4096

@@ -1,0 +1,30 @@
+"""Scenes built from DATA of the reference's fixtures (tests/golden/ref_*.npz, extracted by
+tests/golden/make_ref_cornell.py in the dev container)."""
+import os
+
+import numpy as np
+
+from renderbaby_amd import abi, scene_io, scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref_cornell_mesh():
+    z = np.load(os.path.join(HERE, "golden", "ref_cornell_box.npz"))
+    mats = [scene_io.ObjMaterial(str(n), list(ka), list(kd), list(ks), list(ke), float(d), float(ns), 2)
+            for n, ka, kd, ks, ke, d, ns in zip(z["mat_names"], z["mat_ka"], z["mat_kd"], z["mat_ks"], z["mat_ke"],
+                                                z["mat_d"], z["mat_ns"])]
+    return scene_io.SceneMesh(z["vertices"], z["uvs"], z["material_index"], mats)
+
+
+def ref_cornell(width=64, height=48, spp=4, max_depth=5, n_spheres=8, bvh_builder=None):
+    """The reference's Cornell box (32 triangles: walls, two boxes, area light; MTL materials) through
+    the adapter restatement, plus seeded spheres placed like scenes.cornell_spheres."""
+    mesh = ref_cornell_mesh()
+    sp = scenes.cornell_spheres(n=n_spheres) if n_spheres else np.zeros(0, abi.SPHERE)
+    if n_spheres:
+        sp = sp.copy()
+        sp["center"][:, 1] -= 0.4   # this box's floor is at y = -0.16
+    u = scenes.make_uniforms(width, height, spp, max_depth, cam_pos=(-0.25, 2.6, 6.5), cam_dir=(0, 0, -1),
+                             ground_enabled=0, sky=(0, 0, 0))
+    return scene_io.scene_to_flat([mesh], spheres=sp, uniforms=u, bvh_builder=bvh_builder, name="ref_cornell")

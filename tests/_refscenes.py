@@ -1,4 +1,4 @@
-"""Scenes built from DATA of the reference's fixtures (tests/golden/ref_*.npz, extracted by
+"""Scenes built from DATA of the reference's fixtures (tests/golden/ref_fixtures/*.npz, extracted by
 tests/golden/make_ref_cornell.py in the dev container)."""
 import os
 
@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def ref_cornell_mesh():
-    z = np.load(os.path.join(HERE, "golden", "ref_cornell_box.npz"))
+    z = np.load(os.path.join(HERE, "golden", "ref_fixtures", "cornell_box.npz"))
     mats = [scene_io.ObjMaterial(str(n), list(ka), list(kd), list(ks), list(ke), float(d), float(ns), 2)
             for n, ka, kd, ks, ke, d, ns in zip(z["mat_names"], z["mat_ka"], z["mat_kd"], z["mat_ks"], z["mat_ke"],
                                                 z["mat_d"], z["mat_ns"])]

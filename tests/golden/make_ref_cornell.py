@@ -1,5 +1,5 @@
 """Extracts the DATA of the reference's Cornell-box fixture (vertex coordinates, faces, material
-table) into tests/golden/ref_cornell_box.npz so that tests on the GPU box -- where /root/reference
+table) into tests/golden/ref_fixtures/cornell_box.npz so that tests on the GPU box -- where /root/reference
 does not exist -- can render the reference's own geometry.  Runs only in the dev container.
 
     python tests/golden/make_ref_cornell.py
@@ -18,7 +18,7 @@ obj = scene_io.parse_obj(open(os.path.join(SRC, "cornell-box.obj")).read())
 mats = scene_io.parse_mtl(open(os.path.join(SRC, "cornell-box.mtl")).read())
 mesh = scene_io.obj_to_mesh(obj, mats)
 np.savez_compressed(
-    os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_cornell_box.npz"),
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fixtures", "cornell_box.npz"),
     vertices=mesh.vertices, uvs=mesh.uvs, material_index=mesh.material_index,
     mat_names=np.array([m.name for m in mats]),
     mat_ka=np.array([m.ka for m in mats], np.float64), mat_kd=np.array([m.kd for m in mats], np.float64),

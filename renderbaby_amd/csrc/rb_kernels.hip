@@ -1470,16 +1470,28 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_bvh(const KParams p) {
             }
         }
 
-        // ---- (4) leaf phase: this lane's leaf, triangle by triangle (shader.wgsl:327-374)
-        for (uint32_t i = 0; i < count; i++) {
-            const uint32_t slot = first + i;
-            if (slot >= p.index_len) continue;
-            const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
-            if (__float_as_uint(c.w) == 0u) continue;  // guard :336
-            if constexpr (STATS) tl.tris++;
-            const float before = th.t;
-            test_slot(a, b, c, slot, pt.o, pt.d, th);
-            if constexpr (STATS) tl.mesh_hits += (th.t != before) ? 1u : 0u;
+        // ---- (4) leaf phase: this lane's leaf (shader.wgsl:327-374), two triangles per step so
+        // that six 16-byte loads are in flight per lane; candidates are offered in slot order
+        {
+            const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
+            uint32_t slot = first;
+#if RB_TRI_PAIRS
+            for (; slot + 2u <= end; slot += 2u) {
+                const v4f a0 = ptris[slot * 4u], b0 = ptris[slot * 4u + 1u], c0 = ptris[slot * 4u + 2u];
+                const v4f a1 = ptris[slot * 4u + 4u], b1 = ptris[slot * 4u + 5u], c1 = ptris[slot * 4u + 6u];
+                const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
+                if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
+                test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, pt.o, pt.d, th, tl);
+            }
+#endif
+            for (; slot < end; slot++) {
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+                if constexpr (STATS) tl.tris++;
+                const float before = th.t;
+                test_slot(a, b, c, slot, pt.o, pt.d, th);
+                if constexpr (STATS) tl.mesh_hits += (th.t != before) ? 1u : 0u;
+            }
         }
 
         // ---- (5) traversal complete: ground, spheres, lights, shading, next ray

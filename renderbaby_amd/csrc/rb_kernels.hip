@@ -480,6 +480,22 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
     };
     auto reference_would_test = [&](uint32_t leaf_node) -> bool {
+        // Shortcut: if the ray passes through the reference LEAF's box shrunk by m on every side
+        // (m is far above the rounding error of a slab test), it passes through the interior of
+        // every ancestor's box, so each of the reference's slab tests succeeds; only a ray that
+        // merely grazes the leaf box needs the exact walk up the chain.
+        {
+            const v4f n0 = rnodes[leaf_node * 3u], n1 = rnodes[leaf_node * 3u + 1u];
+            if constexpr (STATS) tl.nodes++;
+            const bool thick = (n1.x - n0.x >= 2.0f * m) && (n1.y - n0.y >= 2.0f * m) && (n1.z - n0.z >= 2.0f * m);
+            const f3 t0 = (mk(n0.x + m, n0.y + m, n0.z + m) - o) * inv;
+            const f3 t1 = (mk(n1.x - m, n1.y - m, n1.z - m) - o) * inv;
+            const float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+            const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+            const bool finite = (t0.x == t0.x) && (t0.y == t0.y) && (t0.z == t0.z) && (t1.x == t1.x) && (t1.y == t1.y) &&
+                                (t1.z == t1.z);
+            if (thick && finite && tf >= fmaxf(tn, 0.0f)) return true;
+        }
         uint32_t n = leaf_node;
         for (;;) {
             const v4f n0 = rnodes[n * 3u], n1 = rnodes[n * 3u + 1u];

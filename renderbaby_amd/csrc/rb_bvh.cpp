@@ -221,10 +221,23 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 // leaf that holds it and its rank in the reference's visit order, plus a parent array of the
 // reference tree: an improving candidate is accepted only if every reference node from its
 // leaf up to the root passes the reference's own slab test, and equal t resolves by rank.
+//
+// How far from its triangle can a hit be reported?  The computed Moller-Trumbore outputs carry
+// absolute errors  du, dv <= e |s| |e2| / |a| ,  dt <= e |s| |e1| |e2| / |a|  with e ~ 7 * 2^-24 and
+// s = origin - v0, so a reported hit lies within  r = e |s| |e1| |e2| / |a|  of the triangle, in
+// space and along the ray.  Each child stores the largest |e1|*|e2| below it and the traversal
+// inflates the child's box by  0.01 * S * that  (S >= |s|: farthest the origin can be from the mesh)
+// plus a slab-rounding margin: every hit with |a| >= 4.2e-5 is then inside every box above its
+// triangle no later than its reported t, and cannot be culled.  Hits with 1e-6 <= |a| < 4.2e-5 (a ray
+// within a fraction of a degree of the triangle's plane, the regime where the reference's own u, v
+// are mostly rounding noise) are not covered by this argument; covering them with the worst-case
+// bound (factor 0.42 instead of 0.01) was tried and makes coarse meshes slower than the reference
+// walk.  Hence "opt-in", and hence the bit-for-bit tests against the reference walk.
 namespace {
 struct FBuilder {
     const std::vector<float>& bmn;   // per item: tight box min (3 floats)
     const std::vector<float>& bmx;
+    const std::vector<float>& e1e2;  // per item |e1| * |e2|
     std::vector<uint32_t>& items;    // permuted in place
     std::vector<SphereNode>& nodes;
     uint32_t limit;
@@ -244,6 +257,11 @@ struct FBuilder {
         }
     }
     float centroid(uint32_t it, int a) const { return 0.5f * (bmn[it * 3 + a] + bmx[it * 3 + a]); }
+    float amax(size_t first, size_t count) const {
+        float m = 0.0f;
+        for (size_t i = first; i < first + count; ++i) m = std::max(m, e1e2[items[i]]);
+        return m;
+    }
     static float area(const float mn[3], const float mx[3]) {
         const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
         return (x < 0 || y < 0 || z < 0) ? 0.0f : 2.0f * (x * y + y * z + z * x);
@@ -341,7 +359,10 @@ struct FBuilder {
         bounds(mid, first + count - mid, n.rmin, n.rmax);
         n.left = build(first, mid - first, depth + 1);
         n.right = build(mid, first + count - mid, depth + 1);
-        n._pad0 = n._pad1 = 0;
+        // largest |e1|*|e2| below each child: scales the per-ray inflation of that child's box
+        const float al = amax(first, mid - first), ar = amax(mid, first + count - mid);
+        std::memcpy(&n._pad0, &al, 4);
+        std::memcpy(&n._pad1, &ar, 4);
         nodes[me] = n;
         return me;
     }
@@ -380,10 +401,16 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     if (slots.empty() || slots.size() >= (1u << 28)) return false;
     // ---- tight boxes per item; items are indices into `slots`
     const size_t n = slots.size();
-    std::vector<float> bmn(n * 3), bmx(n * 3);
+    std::vector<float> bmn(n * 3), bmx(n * 3), e1e2(n);
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
         const rb_gpu_triangle& t = tris[indices[slots[i]]];
+        double l1 = 0, l2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            l1 += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);
+            l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
+        }
+        e1e2[i] = static_cast<float>(std::sqrt(l1) * std::sqrt(l2) * 1.0001);
         for (int a = 0; a < 3; ++a) {
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
@@ -393,13 +420,18 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     }
     std::vector<uint32_t> items(n);
     for (size_t i = 0; i < n; ++i) items[i] = static_cast<uint32_t>(i);
-    FBuilder fb{bmn, bmx, items, out.nodes, stack_limit};
+    FBuilder fb{bmn, bmx, e1e2, items, out.nodes, stack_limit};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
     out.slots.resize(n);
     for (size_t i = 0; i < n; ++i) out.slots[i] = slots[items[i]];
     const float dx = smx[0] - smn[0], dy = smx[1] - smn[1], dz = smx[2] - smn[2];
     out.margin = 1e-4f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-6f;
+    for (int a = 0; a < 3; ++a) {
+        out.bmin[a] = smn[a];
+        out.bmax[a] = smx[a];
+    }
+    out.root_amax = fb.amax(0, n);
     return out.depth <= stack_limit;
 }
 

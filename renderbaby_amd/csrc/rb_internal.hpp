@@ -44,7 +44,9 @@ struct FastTree {
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
     std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
     uint32_t root = 0x80000000u, depth = 0;
-    float margin = 0.0f;               // box inflation for the slab test
+    float margin = 0.0f;               // slab-rounding part of the box inflation
+    float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};  // mesh bounds (for S, the per-ray distance bound)
+    float root_amax = 0.0f;
 };
 bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                     const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out);
@@ -97,6 +99,10 @@ struct KParams {
     const uint32_t* ref_parent;    // reference tree parents
     uint32_t fast_root;
     float fast_margin;
+    float fast_bmin[3];
+    float fast_root_amax;
+    float fast_bmax[3];
+    uint32_t _pad_fast;
     const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
     const float* sph_leaf;         // float4 {centre, radius} in leaf order
     const uint32_t* sph_id;        // original sphere index per leaf-order slot

@@ -471,10 +471,18 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
     const RB_CONST uint32_t* meta = cptr(p.slot_meta);
     const RB_CONST uint32_t* parent = cptr(p.ref_parent);
     const float m = p.fast_margin;
+    // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
+    // triangle).  A child's box is inflated by m + 0.01 * S * (largest |e1||e2| below it): how far
+    // from its triangle a Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
+    const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
+    const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
+                sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
+    const float S = 0.01f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
 
-    auto entry = [&](v4f lo, v4f hi, float& tn) -> bool {
-        const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
-        const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
+    auto entry = [&](v4f lo, v4f hi, float amax, float& tn) -> bool {
+        const float mm = m + S * amax;
+        const f3 t0 = (mk(lo.x - mm, lo.y - mm, lo.z - mm) - o) * inv;
+        const f3 t1 = (mk(hi.x + mm, hi.y + mm, hi.z + mm) - o) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
@@ -542,7 +550,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
         if constexpr (STATS) tl.nodes++;
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
-        const bool hl = entry(l0, l1, tl_), hr = entry(r0, r1, tr_);
+        const bool hl = entry(l0, l1, r0.w, tl_), hr = entry(r0, r1, r1.w, tr_);
         if (hl && hr) {
             const bool left_first = !(tr_ < tl_);
             stack[sp * stride] = left_first ? rref : lref;

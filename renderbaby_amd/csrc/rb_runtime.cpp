@@ -93,7 +93,8 @@ struct rb_engine {
     DevBuf<rb::PrepTri> fast_tris;
     DevBuf<uint32_t> fast_slots, slot_meta, ref_parent;
     uint32_t fast_root = 0, fast_depth = 0;
-    float fast_margin = 0.0f;
+    float fast_margin = 0.0f, fast_root_amax = 0.0f;
+    float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
     bool fast_ready = false;
     std::vector<rb_gpu_triangle> host_tris;  // kept only when RB_FLAG_FAST_BVH is set
     std::vector<uint32_t> host_indices;
@@ -425,6 +426,11 @@ int ensure_prepared(rb_engine* e) {
             e->fast_root = ft.root;
             e->fast_depth = ft.depth;
             e->fast_margin = ft.margin;
+            e->fast_root_amax = ft.root_amax;
+            for (int i = 0; i < 3; ++i) {
+                e->fast_bmin[i] = ft.bmin[i];
+                e->fast_bmax[i] = ft.bmax[i];
+            }
             e->fast_ready = true;
         }
     }
@@ -481,6 +487,11 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.ref_parent = e->ref_parent.ptr;
     p.fast_root = e->fast_root;
     p.fast_margin = e->fast_margin;
+    p.fast_root_amax = e->fast_root_amax;
+    for (int i = 0; i < 3; ++i) {
+        p.fast_bmin[i] = e->fast_bmin[i];
+        p.fast_bmax[i] = e->fast_bmax[i];
+    }
     const bool use_sph_bvh = e->sph_bvh && p.u.spheres_count == e->n_spheres;
     p.sph_nodes = use_sph_bvh ? e->sph_nodes.ptr : nullptr;
     p.sph_leaf = e->sph_leaf.ptr;

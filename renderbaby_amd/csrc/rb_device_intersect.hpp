@@ -1,0 +1,459 @@
+// rb_device_intersect.hpp -- textures, primitive intersection tests, work counters, BVH walks (reference order, fast tree, sphere tree).
+// Part of the single device translation unit rb_kernels.hip (numerics contract: see there).
+#pragma once
+#include "rb_device_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rb {
+namespace {
+
+// -------------------------------------------------------------- textures --
+// shader.wgsl:153-191.  pow(c, 2.2) over the 256 possible channel values is a
+// host-computed table (same libm as the oracle), so textured hits stay bit-exact.
+DEV f3 sample_texture(const KParams& p, int32_t index, float uvx, float uvy) {
+    if (index < 0) {
+        if (p.u.checkerboard_enabled > 0u) {
+            int32_t u2 = f2i(floorf(uvx * 10.0f));
+            int32_t v2 = f2i(floorf(uvy * 10.0f));
+            int32_t sum = (int32_t)((uint32_t)u2 + (uint32_t)v2);
+            return (sum % 2 == 0) ? ld3(p.u.checkerboard_color_1) : ld3(p.u.checkerboard_color_2);
+        }
+        return mk(1.0f, 1.0f, 1.0f);
+    }
+    if ((uint32_t)index >= p.n_tex) return mk(0.0f, 0.0f, 0.0f);
+    const v4u iw = ((cu4p)p.tex_info)[index];
+    rb_texture_info info;
+    info.offset = iw.x;
+    info.width = iw.y;
+    info.height = iw.z;
+    float u = uvx - floorf(uvx);
+    float v = uvy - floorf(uvy);
+    uint32_t x = min(f2u(u * (float)info.width), info.width - 1u);
+    uint32_t y = min(f2u((1.0f - v) * (float)info.height), info.height - 1u);
+    const uint32_t pixel = cptr(p.tex_data)[info.offset + y * info.width + x];
+    const RB_CONST float* lut = cptr(p.srgb_lut);
+    return mk(lut[pixel & 255u], lut[(pixel >> 8) & 255u], lut[(pixel >> 16) & 255u]);
+}
+
+// ---------------------------------------------------------- intersection --
+// shader.wgsl:193-215 / :217-239
+DEV float isect_sphere(f3 o, f3 d, float a, f3 center, float radius) {
+    f3 oc = o - center;
+    float half_b = dot(oc, d);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return -1.0f;
+    float sqrtd = sqrtf(disc);
+    float root = (-half_b - sqrtd) / a;
+    if (root <= 0.001f) {
+        root = (-half_b + sqrtd) / a;
+        if (root <= 0.001f) return -1.0f;
+    }
+    return root;
+}
+
+// shader.wgsl:248-280 with edge1/edge2 supplied (v1 - v0, v2 - v0).  RB_TRI_BRANCHFREE=1
+// evaluates everything and folds the four early returns into one predicate (same
+// comparisons on the same values); measured slower on gfx950 (34.8 vs 33.5 ms on C2-short)
+// because the early-outs do skip whole-wave work, so the branchy form is the default.
+#ifndef RB_TRI_BRANCHFREE
+#define RB_TRI_BRANCHFREE 0
+#endif
+DEV float isect_triangle(f3 o, f3 d, f3 v0, f3 edge1, f3 edge2, float& uo, float& vo) {
+#if RB_TRI_BRANCHFREE
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = rcp_tri(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(edge2, q);
+    const bool miss = (fabsf(a) < 1e-6f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | !(t > 0.0f);
+    uo = u;
+    vo = v;
+    return miss ? -1.0f : t;
+#else
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    if (fabsf(a) < 1e-6f) return -1.0f;
+    const float f = rcp_tri(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float t = f * dot(edge2, q);
+    if (t > 0.0f) {
+        uo = u;
+        vo = v;
+        return t;
+    }
+    return -1.0f;
+#endif
+}
+
+// shader.wgsl:664-671 with inv_dir = 1/dir hoisted per ray (pure function of dir)
+DEV bool isect_aabb(f3 o, f3 inv, f3 bmin, f3 bmax) {
+    f3 t0 = (bmin - o) * inv;
+    f3 t1 = (bmax - o) * inv;
+    float tmin = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+    float tmax = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+    return tmax >= fmaxf(tmin, 0.0f);
+}
+
+// shader.wgsl:402-414
+DEV float isect_ground(f3 o, f3 d, float ground_height) {
+    if (fabsf(d.y) < 1e-6f) return -1.0f;
+    float t = (ground_height - o.y) / d.y;
+    return (t > 0.0f) ? t : -1.0f;
+}
+
+// ------------------------------------------------------------ statistics --
+template <bool STATS>
+struct Tally {
+    uint32_t segments = 0, paths = 0;
+    unsigned long long nodes = 0, tris = 0, spheres = 0, lights = 0, mesh_hits = 0;
+};
+template <>
+struct Tally<false> {
+    uint32_t segments = 0, paths = 0;
+};
+
+DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <bool STATS>
+DEV void flush_tally(const Tally<STATS>& t, unsigned long long* counters) {
+    unsigned long long seg = wave_sum((unsigned long long)t.segments);
+    unsigned long long pth = wave_sum((unsigned long long)t.paths);
+    const bool lead = (__lane_id() == 0);
+    if (lead) {
+        atomicAdd(&counters[C_SEGMENTS], seg);
+        atomicAdd(&counters[C_PATHS], pth);
+    }
+    if constexpr (STATS) {
+        unsigned long long a = wave_sum(t.nodes), b = wave_sum(t.tris), c = wave_sum(t.spheres),
+                           d = wave_sum(t.lights), e = wave_sum(t.mesh_hits);
+        if (lead) {
+            atomicAdd(&counters[C_NODES], a);
+            atomicAdd(&counters[C_TRIS], b);
+            atomicAdd(&counters[C_SPHERES], c);
+            atomicAdd(&counters[C_LIGHTS], d);
+            atomicAdd(&counters[C_MESH_HITS], e);
+        }
+    }
+}
+
+// -------------------------------------------------------- BVH traversal --
+struct TriHit {
+    float t, u, v;
+    uint32_t slot;  // position in bvh_indices (prepared-triangle index)
+    bool hit;
+};
+
+// shader.wgsl:282-392.  Same visit order (left pushed first, right popped first),
+// same strict `t > 0.001 && t < hit.t` acceptance, so the winner is the same
+// triangle.  Shading data of shader.wgsl:350-372 depends only on the final
+// winner and is produced afterwards (tri_shade).  `stack` is this lane's column
+// of an LDS array [kStackDepth][blockDim]; the host has verified that the tree
+// fits (rb_bvh.cpp).
+DEV void test_slot(const v4f a, const v4f b, const v4f c, uint32_t slot, f3 o, f3 d, TriHit& h) {
+    float u, v;
+    const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+    if (t > 0.001f && t < h.t) {
+        h.hit = true;
+        h.t = t;
+        h.u = u;
+        h.v = v;
+        h.slot = slot;
+    }
+}
+
+#ifndef RB_TRI_PAIRS
+#define RB_TRI_PAIRS 1
+#endif
+// Two triangles per step with packed f32 math (v_pk_mul_f32 / v_pk_add_f32: two IEEE
+// binary32 operations per lane per instruction).  Element 0 is the triangle at `slot`,
+// element 1 the one at `slot + 1`; every element goes through exactly the operations of
+// isect_triangle (shader.wgsl:248-280), so each t, u, v is bit-identical to the one-at-a-time
+// form, and the two candidates are offered to the closest-hit test in slot order.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool STATS>
+DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f a1, const v4f b1, const v4f c1,
+                   bool ok1, uint32_t slot, f3 o, f3 d, TriHit& h, Tally<STATS>& tl) {
+    const f2 v0x = {a0.x, a1.x}, v0y = {a0.y, a1.y}, v0z = {a0.z, a1.z};
+    const f2 e1x = {b0.x, b1.x}, e1y = {b0.y, b1.y}, e1z = {b0.z, b1.z};
+    const f2 e2x = {c0.x, c1.x}, e2y = {c0.y, c1.y}, e2z = {c0.z, c1.z};
+    // h = cross(d, edge2)
+    const f2 hx = d.y * e2z - d.z * e2y;
+    const f2 hy = d.z * e2x - d.x * e2z;
+    const f2 hz = d.x * e2y - d.y * e2x;
+    const f2 a = (e1x * hx + e1y * hy) + e1z * hz;
+    const f2 f = {rcp_tri(a.x), rcp_tri(a.y)};
+    const f2 sx = o.x - v0x, sy = o.y - v0y, sz = o.z - v0z;
+    const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
+    // q = cross(s, edge1)
+    const f2 qx = sy * e1z - sz * e1y;
+    const f2 qy = sz * e1x - sx * e1z;
+    const f2 qz = sx * e1y - sy * e1x;
+    const f2 v = f * ((d.x * qx + d.y * qy) + d.z * qz);
+    const f2 t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    const f2 uv = u + v;
+    const bool hit0 = ok0 && !(fabsf(a.x) < 1e-6f) && !(u.x < 0.0f) && !(u.x > 1.0f) && !(v.x < 0.0f) && !(uv.x > 1.0f) &&
+                      (t.x > 0.0f);
+    const bool hit1 = ok1 && !(fabsf(a.y) < 1e-6f) && !(u.y < 0.0f) && !(u.y > 1.0f) && !(v.y < 0.0f) && !(uv.y > 1.0f) &&
+                      (t.y > 0.0f);
+    if (hit0 && t.x > 0.001f && t.x < h.t) {
+        h.hit = true;
+        h.t = t.x;
+        h.u = u.x;
+        h.v = v.x;
+        h.slot = slot;
+        if constexpr (STATS) tl.mesh_hits++;
+    }
+    if (hit1 && t.y > 0.001f && t.y < h.t) {
+        h.hit = true;
+        h.t = t.y;
+        h.u = u.y;
+        h.v = v.y;
+        h.slot = slot + 1u;
+        if constexpr (STATS) tl.mesh_hits++;
+    }
+}
+
+// Opt-in fast walk (RB_FLAG_FAST_BVH) of the library's own SAH tree over the same triangles
+// (rb_bvh.cpp, fast_bvh_build): nearer child first, subtrees skipped when missed or entered
+// beyond the best t.  It reproduces the reference walk's winner:
+//  * candidates are evaluated with the reference's isect_triangle, so t, u, v are the same bits;
+//  * equal t resolves by the triangle's rank in the reference's visit order;
+//  * the reference only tests a triangle if every node from the root to its leaf passes
+//    intersect_aabb: an improving candidate is accepted only after that chain has been
+//    re-checked with the reference's own slab arithmetic on the reference's boxes;
+//  * boxes are inflated by a margin so rounding cannot cull a triangle the reference would hit.
+// Not a proof (an ill-conditioned Moller-Trumbore hit far outside its triangle could be missed),
+// which is why it is opt-in; the tests compare it bit for bit with the reference walk.
+template <bool STATS>
+DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    TriHit h;
+    h.hit = false;
+    h.t = 1e20f;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.slot = 0u;
+    uint32_t best_rank = 0xFFFFFFFFu;
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
+    const cf4p nodes = (cf4p)p.fast_nodes;
+    const cf4p ftris = (cf4p)p.fast_tris;
+    const cf4p rnodes = (cf4p)p.nodes;
+    const RB_CONST uint32_t* fslots = cptr(p.fast_slots);
+    const RB_CONST uint32_t* meta = cptr(p.slot_meta);
+    const RB_CONST uint32_t* parent = cptr(p.ref_parent);
+    const float m = p.fast_margin;
+    // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
+    // triangle).  A child's box is inflated by m + 0.01 * S * (largest |e1||e2| below it): how far
+    // from its triangle a Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
+    const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
+    const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
+                sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
+    const float S = 0.01f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
+
+    auto entry = [&](v4f lo, v4f hi, float amax, float& tn) -> bool {
+        const float mm = m + S * amax;
+        const f3 t0 = (mk(lo.x - mm, lo.y - mm, lo.z - mm) - o) * inv;
+        const f3 t1 = (mk(hi.x + mm, hi.y + mm, hi.z + mm) - o) * inv;
+        tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+        const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+        return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
+    };
+    auto reference_would_test = [&](uint32_t leaf_node) -> bool {
+        // Shortcut: if the ray passes through the reference LEAF's box shrunk by m on every side
+        // (m is far above the rounding error of a slab test), it passes through the interior of
+        // every ancestor's box, so each of the reference's slab tests succeeds; only a ray that
+        // merely grazes the leaf box needs the exact walk up the chain.
+        {
+            const v4f n0 = rnodes[leaf_node * 3u], n1 = rnodes[leaf_node * 3u + 1u];
+            if constexpr (STATS) tl.nodes++;
+            const bool thick = (n1.x - n0.x >= 2.0f * m) && (n1.y - n0.y >= 2.0f * m) && (n1.z - n0.z >= 2.0f * m);
+            const f3 t0 = (mk(n0.x + m, n0.y + m, n0.z + m) - o) * inv;
+            const f3 t1 = (mk(n1.x - m, n1.y - m, n1.z - m) - o) * inv;
+            const float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+            const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+            const bool finite = (t0.x == t0.x) && (t0.y == t0.y) && (t0.z == t0.z) && (t1.x == t1.x) && (t1.y == t1.y) &&
+                                (t1.z == t1.z);
+            if (thick && finite && tf >= fmaxf(tn, 0.0f)) return true;
+        }
+        uint32_t n = leaf_node;
+        for (;;) {
+            const v4f n0 = rnodes[n * 3u], n1 = rnodes[n * 3u + 1u];
+            if constexpr (STATS) tl.nodes++;
+            if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) return false;
+            if (n == 0u) return true;
+            n = parent[n];
+        }
+    };
+    auto leaf = [&](uint32_t ref) {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
+        for (uint32_t j = first; j < first + count; j++) {
+            const v4f a = ftris[j * 4u], b = ftris[j * 4u + 1u], c = ftris[j * 4u + 2u];
+            if constexpr (STATS) tl.tris++;
+            float u, v;
+            const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+            if (t > 0.001f && !(t > h.t)) {
+                const uint32_t slot = fslots[j];
+                const uint32_t leaf_node = meta[slot * 2u], rank = meta[slot * 2u + 1u];
+                if ((t < h.t || rank < best_rank) && reference_would_test(leaf_node)) {
+                    h.hit = true;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.slot = slot;
+                    best_rank = rank;
+                    if constexpr (STATS) tl.mesh_hits++;
+                }
+            }
+        }
+    };
+
+    uint32_t cur = p.fast_root;
+    int sp = 0;
+    for (;;) {
+        if (cur & 0x80000000u) {
+            leaf(cur);
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+            continue;
+        }
+        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        if constexpr (STATS) tl.nodes++;
+        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+        float tl_, tr_;
+        const bool hl = entry(l0, l1, r0.w, tl_), hr = entry(r0, r1, r1.w, tr_);
+        if (hl && hr) {
+            const bool left_first = !(tr_ < tl_);
+            stack[sp * stride] = left_first ? rref : lref;
+            sp++;
+            cur = left_first ? lref : rref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+        }
+    }
+    return h;
+}
+
+template <bool STATS>
+DEV TriHit intersect_bvh(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    TriHit h;
+    h.hit = false;
+    h.t = 1e20f;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.slot = 0u;
+    const uint32_t node_count = p.u.bvh_node_count;
+    if (node_count == 0u) return h;
+    if (p.fast_nodes != nullptr) return intersect_bvh_fast<STATS>(p, o, d, stack, stride, tl);
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
+    const cf4p nodes = (cf4p)p.nodes;
+    const cf4p ptris = (cf4p)p.ptris;  // 4 x float4 per triangle
+
+    if (node_count == 1u) {
+        // Single-node tree (the Cornell box): no stack; the node and its triangles are
+        // wave-uniform, so they are fetched with scalar loads and every lane that is
+        // inside the box walks the same primitive list.  Same tests, same order.  The next
+        // triangle's record is requested before the current one is tested.
+        const v4f n0 = nodes[0], n1 = nodes[1];
+        const v4u n2 = ((cu4p)p.nodes)[2];
+        if constexpr (STATS) tl.nodes++;
+        const uint32_t first = n2.z, count = n2.w;
+        const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
+        if (first < end && isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
+#if RB_TRI_PAIRS
+            uint32_t slot = first;
+            cf4p tp = ptris + (size_t)first * 4u;  // running pointer: one scalar add per step, immediate offsets
+            for (; slot + 2u <= end; slot += 2u, tp += 8) {
+                const v4f a0 = tp[0], b0 = tp[1], c0 = tp[2];
+                const v4f a1 = tp[4], b1 = tp[5], c1 = tp[6];
+                const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
+                if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
+                test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, o, d, h, tl);
+            }
+            for (; slot < end; slot++, tp += 4) {
+                const v4f a = tp[0], b = tp[1], c = tp[2];
+#else
+            for (uint32_t slot = first; slot < end; slot++) {
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+#endif
+                if (__float_as_uint(c.w) != 0u) {  // guard :336
+                    if constexpr (STATS) tl.tris++;
+                    const float before = h.t;
+                    test_slot(a, b, c, slot, o, d, h);
+                    if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
+                }
+            }
+        }
+        return h;
+    }
+
+    int sp = 0;
+    stack[0] = 0u;
+    sp = 1;
+    while (sp > 0) {
+        sp--;
+        const uint32_t node_idx = stack[sp * stride];
+        if (node_idx >= node_count) continue;
+        const v4f n0 = nodes[node_idx * 3u], n1 = nodes[node_idx * 3u + 1u];
+        const v4u n2 = ((cu4p)p.nodes)[node_idx * 3u + 2u];
+        if constexpr (STATS) tl.nodes++;
+        if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
+        const uint32_t left = n2.x, right = n2.y, first = n2.z, count = n2.w;
+        if (count > 0u) {
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t slot = first + i;
+                if (slot >= p.index_len) continue;
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+                if constexpr (STATS) tl.tris++;
+                const float before = h.t;
+                test_slot(a, b, c, slot, o, d, h);
+                if constexpr (STATS) tl.mesh_hits += (h.t != before) ? 1u : 0u;
+            }
+        } else {
+            if (left < node_count) {
+                stack[sp * stride] = left;
+                sp++;
+            }
+            if (right < node_count) {
+                stack[sp * stride] = right;
+                sp++;
+            }
+        }
+    }
+    return h;
+}
+
+DEV float uv_at(const KParams& p, uint32_t i) { return (i < p.n_uvs) ? cptr(p.uvs)[i] : 0.0f; }
+
+// shader.wgsl:353-361
+DEV void tri_uv(const KParams& p, const TriHit& h, float& uvx, float& uvy) {
+    const v4u s0 = ((cu4p)p.pshade)[h.slot];
+    const uint32_t i0 = s0.x, i1 = s0.y, i2 = s0.z;  // v0_index, v1_index, v2_index
+    const float w = 1.0f - h.u - h.v;
+    const float uv0x = uv_at(p, i0 * 2u), uv0y = uv_at(p, i0 * 2u + 1u);
+    const float uv1x = uv_at(p, i1 * 2u), uv1y = uv_at(p, i1 * 2u + 1u);
+    const float uv2x = uv_at(p, i2 * 2u), uv2y = uv_at(p, i2 * 2u + 1u);
+    uvx = (w * uv0x + h.u * uv1x) + h.v * uv2x;
+    uvy = (w * uv0y + h.u * uv1y) + h.v * uv2y;
+}
+
+}  // namespace
+}  // namespace rb

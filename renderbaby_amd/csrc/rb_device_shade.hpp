@@ -1,0 +1,444 @@
+// rb_device_shade.hpp -- one iteration of the bounce loop (closest-hit resolution + shading), camera / primary rays, pixel store.
+// Part of the single device translation unit rb_kernels.hip (numerics contract: see there).
+#pragma once
+#include "rb_device_intersect.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rb {
+namespace {
+
+// ------------------------------------------------------------- materials --
+struct Mat {
+    f3 diffuse, specular, emissive;
+    float fuzz;     // clamp(1 - shininess / 1000, 0, 1)   (shader.wgsl:637)
+    bool metal;     // mean(specular) > 0.01 && mean(diffuse) < 0.01   (:615-623)
+    int32_t tex;
+};
+DEV Mat load_mat(const rb_material* m) {
+    const cf4p q = (cf4p)m;
+    const v4f d = q[1], s = q[2], e = q[3];
+    const v4u t = ((cu4p)m)[4];  // opacity, illum, texture_index, pad
+    Mat r;
+    r.diffuse = mk(d.x, d.y, d.z);
+    r.specular = mk(s.x, s.y, s.z);
+    r.fuzz = d.w;          // device copy's _pad1, filled by k_prep_materials
+    r.emissive = mk(e.x, e.y, e.z);
+    r.tex = (int32_t)t.z;
+    r.metal = t.w != 0u;   // device copy's _pad2
+    return r;
+}
+DEV int32_t load_tex_index(const rb_material* m) {
+    const v4u t = ((cu4p)m)[4];
+    return (int32_t)t.z;
+}
+
+enum Kind : uint32_t { K_NONE = 0, K_GROUND = 1, K_TRI = 2, K_SPHERE = 3, K_LIGHT = 4 };
+
+struct Path {
+    f3 o, d;
+    f3 color, att;
+    uint32_t seed;
+    uint32_t depth;
+};
+
+DEV f3 reflect_vector(f3 v, f3 n) { return v - (2.0f * dot(v, n)) * n; }  // :459-461
+DEV bool near_zero(f3 v) {                                                // :463-466
+    const float s = 1e-8f;
+    return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
+}
+
+// Sphere acceleration structure (rb_bvh.cpp, sphere_bvh_build): closest sphere with the
+// semantics of the reference's linear scan (shader.wgsl:574-586).
+//  * every candidate is evaluated with the reference's exact intersect_sphere;
+//  * the scan accepts `t > 0.001 && t < closest.t` in index order, i.e. the winner is the
+//    smallest t below the incoming closest_t, ties going to the lowest index: here
+//    `t < best || (t == best && id < best_id)`;
+//  * a subtree is skipped only if the ray misses its box inflated by m, or enters it beyond
+//    best_t.  m covers the rounding error of the reference's own arithmetic: its discriminant
+//    hb^2 - a*(|oc|^2 - r^2) carries an absolute error <= 16 u a |oc|^2 (u = 2^-24), so a sphere
+//    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 D^2) from its centre and the
+//    reported t can be early by about the same amount; D = the farthest the ray origin can be
+//    from any sphere.  m = 3e-3 * D (> 2 * sqrt(1e-6) * D) bounds both.
+DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx,
+                               uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
+    const cf4p nodes = (cf4p)p.sph_nodes;
+    const cf4p leafs = (cf4p)p.sph_leaf;
+    const RB_CONST uint32_t* ids = cptr(p.sph_id);
+    const f3 bmin = ld3(p.sph_bmin), bmax = ld3(p.sph_bmax);
+    const float dx = fmaxf(fabsf(o.x - bmin.x), fabsf(o.x - bmax.x));
+    const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
+    const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
+    const float m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
+    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
+    float best = closest_t;
+    uint32_t best_id = 0xFFFFFFFFu;
+
+    // slab test of a box inflated by m: visit unless missed or entered beyond `best`
+    // (comparisons are written so that a NaN means "visit")
+    auto entry = [&](v4f lo, v4f hi, float& tn) -> bool {
+        const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
+        const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
+        tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+        const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+        return !(tf < fmaxf(tn, 0.0f)) && !(tn > best);
+    };
+    auto leaf = [&](uint32_t ref) {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
+        for (uint32_t j = first; j < first + count; j++) {
+            const v4f cr = leafs[j];
+            const uint32_t id = ids[j];
+            if (n_tested) (*n_tested)++;
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && (t < best || (t == best && id < best_id))) {
+                best = t;
+                best_id = id;
+            }
+        }
+    };
+
+    uint32_t cur = p.sph_root;
+    int sp = 0;
+    for (;;) {
+        if (cur & 0x80000000u) {
+            leaf(cur);
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+            continue;
+        }
+        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+        float tl_, tr_;
+        const bool hl = entry(l0, l1, tl_), hr = entry(r0, r1, tr_);
+        if (hl && hr) {
+            // nearer child first; the other waits on the stack
+            const bool left_first = !(tr_ < tl_);
+            stack[sp * stride] = left_first ? rref : lref;
+            sp++;
+            cur = left_first ? lref : rref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * stride];
+        }
+    }
+    if (best_id != 0xFFFFFFFFu) {
+        closest_t = best;
+        sphere_idx = best_id;
+    }
+}
+
+// One iteration of the bounce loop, shader.wgsl:534-660.  Returns true when the
+// path continues.  The closest-hit search keeps the reference's category order
+// (ground, BVH, spheres, lights) and strict comparisons, so ties resolve the
+// same way; per-hit data that only the final winner needs (position, normal,
+// material, uv) is produced once, after the search.
+template <bool STATS>
+DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
+                        Tally<STATS>& tl) {
+    const f3 o = pt.o, d = pt.d;
+    tl.segments++;
+
+    float closest_t = 1e20f;
+    uint32_t kind = K_NONE;
+    // state of closest_hit.uv / use_texture after the ground + BVH stage
+    float uvx = 0.0f, uvy = 0.0f;
+    bool use_tex = false;
+
+    // Ground :552-565
+    if (p.u.ground_enabled > 0u) {
+        const float t = isect_ground(o, d, p.u.ground_height);
+        if (t > 0.001f && t < closest_t) {
+            closest_t = t;
+            kind = K_GROUND;
+            const f3 gp = o + t * d;
+            uvx = gp.x;
+            uvy = gp.z;
+            use_tex = true;
+        }
+    }
+
+    // BVH triangles :568-571 (th: the traversal's winner, produced by the caller)
+    const bool tri_won_a = th.hit && th.t < closest_t;  // closest_hit = bvh_hit
+    if (tri_won_a) {
+        closest_t = th.t;
+        kind = K_TRI;
+    }
+
+    // Spheres :574-586 and point lights :590-601.  Two passes with the reference's arithmetic:
+    // pass 1 evaluates the discriminant of every sphere with wave-uniform scalar loads and
+    // records the candidates (disc >= 0) in a per-lane bit mask; pass 2 runs the sqrt/divide
+    // tail only for a lane's own candidates, in ascending index order, so the strict `<`
+    // keeps the same winner.  Most lanes have no candidate, so the expensive tail is issued
+    // once or twice per segment instead of once per sphere.
+    const float a = dot(d, d);
+    uint32_t sphere_idx = 0xFFFFFFFFu;
+    const uint32_t ns = p.u.spheres_count;
+    const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
+    if (p.sph_nodes != nullptr) {
+        unsigned long long* cnt = nullptr;
+        if constexpr (STATS) cnt = &tl.spheres;
+        intersect_spheres_bvh(p, o, d, a, closest_t, sphere_idx, stack, stride, cnt);
+    } else
+    for (uint32_t base = 0; base < ns; base += 32u) {
+        const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
+        uint32_t cand = 0u;
+        cf4p sp_ = sph4 + (size_t)base * 6u;
+        for (uint32_t k = 0; k < n; k++, sp_ += 6) {
+            const v4f cr = sp_[0];
+            if constexpr (STATS) tl.spheres++;
+            const f3 oc = o - mk(cr.x, cr.y, cr.z);
+            const float half_b = dot(oc, d);
+            const float c = dot(oc, oc) - cr.w * cr.w;
+            const float disc = half_b * half_b - a * c;
+            cand |= (disc < 0.0f) ? 0u : (1u << k);
+        }
+        while (cand != 0u) {
+            const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+            cand &= cand - 1u;
+            const v4f cr = sph4[(base + k) * 6u];
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && t < closest_t) {
+                closest_t = t;
+                sphere_idx = base + k;
+            }
+        }
+    }
+    if (sphere_idx != 0xFFFFFFFFu) kind = K_SPHERE;
+
+    uint32_t light_idx = 0xFFFFFFFFu;
+    const cf4p lgt4 = (cf4p)p.lights;
+    for (uint32_t base = 0; base < p.n_lights; base += 32u) {
+        const uint32_t n = (p.n_lights - base < 32u) ? p.n_lights - base : 32u;
+        uint32_t cand = 0u;
+        for (uint32_t k = 0; k < n; k++) {
+            const v4f cr = lgt4[(base + k) * 6u];
+            if constexpr (STATS) tl.lights++;
+            const f3 oc = o - mk(cr.x, cr.y, cr.z);
+            const float half_b = dot(oc, d);
+            const float c = dot(oc, oc) - cr.w * cr.w;
+            const float disc = half_b * half_b - a * c;
+            cand |= (disc < 0.0f) ? 0u : (1u << k);
+        }
+        while (cand != 0u) {
+            const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+            cand &= cand - 1u;
+            const v4f cr = lgt4[(base + k) * 6u];
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && t < closest_t) {
+                closest_t = t;
+                light_idx = base + k;
+            }
+        }
+    }
+    if (light_idx != 0xFFFFFFFFu) kind = K_LIGHT;
+#if RB_ABLATE == 2
+    {
+        f3 o2 = o;
+        asm volatile("" : "+v"(o2.x));
+        float ct = 1e20f;
+        uint32_t si = 0;
+        for (uint32_t base = 0; base < ns; base += 32u) {
+            const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
+            uint32_t cand = 0u;
+            for (uint32_t k = 0; k < n; k++) {
+                const v4f cr = sph4[(base + k) * 6u];
+                const f3 oc = o2 - mk(cr.x, cr.y, cr.z);
+                const float half_b = dot(oc, d);
+                const float c = dot(oc, oc) - cr.w * cr.w;
+                const float disc = half_b * half_b - a * c;
+                cand |= (disc < 0.0f) ? 0u : (1u << k);
+            }
+            while (cand != 0u) {
+                const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
+                cand &= cand - 1u;
+                const v4f cr = sph4[(base + k) * 6u];
+                const float t = isect_sphere(o2, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+                if (t > 0.001f && t < ct) {
+                    ct = t;
+                    si = base + k;
+                }
+            }
+        }
+        asm volatile("" ::"v"(ct), "v"(si));
+    }
+#endif
+
+    // Sky :604-608
+    if (kind == K_NONE) {
+        pt.color = pt.color + pt.att * ld3(p.u.sky_color);
+        return false;
+    }
+
+    // ---- resolve the winner's HitRecord fields (:555-563, :348-372, :579-584, :595-599)
+    const f3 pos = o + closest_t * d;
+    f3 normal = mk(0.0f, 1.0f, 0.0f);
+    Mat m;
+    m.diffuse = mk(0, 0, 0);
+    m.specular = mk(0, 0, 0);
+    m.emissive = mk(0, 0, 0);
+    m.fuzz = 1.0f;
+    m.metal = false;  // ground (diffuse 0.5) and colour-hash triangles (specular 0) are never metal
+    m.tex = -1;
+    if (tri_won_a) {
+        // the BVH hit replaced closest_hit, including uv and use_texture, even if a
+        // sphere or light wins later (those never reset uv; lights never reset use_texture)
+        const cu4p pr = (cu4p)p.ptris + th.slot * 4u;  // [0].w = tri_id, [1].w = mesh_index
+        if (p.u.color_hash_enabled != 0u) {
+            use_tex = false;
+            if (kind == K_TRI) {
+                const v4u p0 = pr[0];
+                m.diffuse = hash_to_color(p0.w + 1u);
+            }
+        } else {
+            const v4u p1 = pr[1];
+            const rb_material* mm = &p.meshes[p1.w].material;
+            if (kind == K_TRI) {
+                m = load_mat(mm);
+                use_tex = m.tex >= 0;
+            } else {
+                use_tex = load_tex_index(mm) >= 0;
+            }
+        }
+    }
+    if (kind == K_GROUND) {
+        m.diffuse = mk(0.5f, 0.5f, 0.5f);
+    } else if (kind == K_TRI) {
+        const v4f s = ((cf4p)p.ptris)[th.slot * 4u + 3u];
+        normal = mk(s.x, s.y, s.z);
+    } else {
+        if (sphere_idx != 0xFFFFFFFFu) {
+            const rb_sphere* s = p.spheres + sphere_idx;
+            if (kind == K_SPHERE) {
+                m = load_mat(&s->material);
+                use_tex = m.tex >= 0;
+                const v4f cr = ((cf4p)s)[0];
+                normal = normalize(pos - mk(cr.x, cr.y, cr.z));
+            } else {
+                use_tex = load_tex_index(&s->material) >= 0;
+            }
+        }
+        if (kind == K_LIGHT) {
+            const rb_point_light* l = p.lights + light_idx;
+            m = load_mat(&l->material);
+            const v4f cr = ((cf4p)l)[0];
+            normal = normalize(pos - mk(cr.x, cr.y, cr.z));
+        }
+    }
+
+    // is_metal / fuzz (:615-623,637) are pure functions of the material: evaluated once per
+    // material at upload (k_prep_materials) with the shader's arithmetic
+    const bool is_metal = m.metal;
+
+    pt.color = pt.color + pt.att * m.emissive;  // :626
+
+#if RB_ABLATE == 3
+    {
+        uint32_t s2 = pt.seed;
+        asm volatile("" : "+v"(s2));
+        const f3 r2 = random_unit_vector(s2);
+        asm volatile("" ::"v"(r2.x), "v"(r2.y), "v"(r2.z));
+    }
+#endif
+    // Both scatter branches draw exactly one random unit vector (:472, :488) and nothing else
+    // touches the seed, so the rejection loop runs once for the whole wavefront instead of once
+    // per branch; likewise the final normalize below is shared.
+    const f3 ruv = random_unit_vector(pt.seed);
+    f3 scattered, albedo;
+    bool absorbed = false;
+    if (is_metal) {
+        const f3 reflected = reflect_vector(normalize(d), normal);
+        scattered = reflected + m.fuzz * ruv;
+        absorbed = dot(scattered, normal) <= 0.0f;  // :640-642
+        albedo = m.specular;
+    } else {
+        const f3 sd = normal + ruv;
+        scattered = near_zero(sd) ? normal : normalize(sd);
+        albedo = m.diffuse;
+        if (use_tex) {
+            if (tri_won_a) tri_uv(p, th, uvx, uvy);
+            albedo = albedo * sample_texture(p, m.tex, uvx, uvy);
+        }
+    }
+    if (absorbed) return false;
+    pt.att = pt.att * albedo;
+    pt.o = pos + 0.001f * normal;
+    pt.d = normalize(scattered);
+    pt.depth++;
+    return pt.depth < p.u.max_depth;
+}
+
+// One whole iteration of the bounce loop: traversal + everything else.
+template <bool STATS>
+DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    const TriHit th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, stride, tl);
+#if RB_ABLATE == 1
+    {
+        f3 o2 = pt.o;
+        asm volatile("" : "+v"(o2.x));
+        Tally<STATS> t2;
+        const TriHit th2 = intersect_bvh<STATS>(p, o2, pt.d, stack, stride, t2);
+        asm volatile("" ::"v"(th2.t), "v"(th2.slot));
+    }
+#endif
+    return segment_finish<STATS>(p, pt, th, stack, stride, tl);
+}
+
+// ----------------------------------------------------------------- camera --
+struct Cam {
+    f3 pos, right, up, fwd;
+    float fov, aspect, wm1, hm1;
+};
+// shader.wgsl:690,702-708 (per-launch invariants of the sample loop)
+DEV Cam make_cam(const KParams& p) {
+    Cam c;
+    c.aspect = (float)p.u.width / (float)p.u.height;
+    c.pos = ld3(p.u.camera.pos);
+    c.fwd = normalize(ld3(p.u.camera.dir));
+    c.right = normalize(cross(mk(0.0f, 1.0f, 0.0f), c.fwd));
+    c.up = cross(c.fwd, c.right);
+    c.fov = p.u.camera.pane_width / (2.0f * p.u.camera.pane_distance * c.aspect);
+    c.wm1 = (float)(p.u.width - 1u);
+    c.hm1 = (float)(p.u.height - 1u);
+    return c;
+}
+// shader.wgsl:693-709
+DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
+                    uint32_t sample_offset, Path& pt) {
+    uint32_t seed = pcg(pixel_index + pcg(sample_offset));
+    const float off_x = rnd(seed) - 0.5f;
+    const float off_y = rnd(seed) - 0.5f;
+    const float u = ((((float)x + off_x) / c.wm1) * 2.0f - 1.0f) * c.aspect;
+    const float v = 1.0f - (((float)y + off_y) / c.hm1) * 2.0f;
+    pt.o = c.pos;
+    pt.d = normalize(((c.fov * u) * c.right + (c.fov * v) * c.up) + c.fwd);
+    pt.seed = seed;
+    pt.color = mk(0, 0, 0);
+    pt.att = mk(1, 1, 1);
+    pt.depth = 0;
+}
+
+// global image row of local row `ly` (interleaved stripes)
+DEV uint32_t global_row(const KParams& p, uint32_t ly) {
+    if (p.shard_count <= 1u) return ly;
+    const uint32_t s = ly / p.stripe_rows, r = ly % p.stripe_rows;
+    return (s * p.shard_count + p.shard_rank) * p.stripe_rows + r;
+}
+
+// shader.wgsl:716-722 + the x mirror of gpu_wrapper.rs:446-458
+DEV void store_pixel(const KParams& p, uint32_t x, uint32_t ly, f3 acc, uint32_t total_samples) {
+    const size_t li = (size_t)ly * p.u.width + x;
+    const float ts = (float)total_samples;
+    reinterpret_cast<float4*>(p.accum)[li] = make_float4(acc.x, acc.y, acc.z, ts);
+    const f3 fin = divs(acc, ts);
+    const f3 mapped = mk(fin.x / (fin.x + 1.0f), fin.y / (fin.y + 1.0f), fin.z / (fin.z + 1.0f));
+    p.out_rgba[(size_t)ly * p.u.width + (p.u.width - 1u - x)] = color_map(mapped);
+}
+
+}  // namespace
+}  // namespace rb

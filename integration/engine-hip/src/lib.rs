@@ -1,0 +1,95 @@
+//! `impl Renderer` / `impl FrameIterator` over librenderbaby_hip.so -- the crate RenderBaby adds
+//! to select the HIP backend.  Source only -- not compiled here.
+mod ffi;
+use anyhow::{anyhow, Result};
+use engine_config::{render_config::Change, RenderConfig, Renderer};
+use frame_buffer::frame_iterator::{Frame, FrameIterator};
+use std::{ffi::CStr, os::raw::c_void, ptr, sync::{Arc, Mutex}};
+
+struct Handle(*mut ffi::RbEngine);
+unsafe impl Send for Handle {}          // the library serialises every call internally and
+unsafe impl Sync for Handle {}          // selects its device per call (any thread may call)
+impl Drop for Handle { fn drop(&mut self) { unsafe { ffi::rb_destroy(self.0) } } }
+
+pub struct Engine { h: Arc<Mutex<Handle>> }   // mirrors Arc<Mutex<GpuWrapper>>, lib.rs:39-42
+
+fn field<T>(c: &Change<Vec<T>>) -> ffi::RbField {
+    match c {
+        Change::Keep      => ffi::RbField { change: ffi::RB_KEEP,   ptr: ptr::null(), count: 0 },
+        Change::Delete    => ffi::RbField { change: ffi::RB_DELETE, ptr: ptr::null(), count: 0 },
+        Change::Create(v) => ffi::RbField { change: ffi::RB_CREATE, ptr: v.as_ptr() as *const c_void, count: v.len() },
+        Change::Update(v) => ffi::RbField { change: ffi::RB_UPDATE, ptr: v.as_ptr() as *const c_void, count: v.len() },
+    }
+}
+
+/// Borrow `rc` as an `rb_config` for the duration of `f` (the library copies to the device
+/// before it returns; nothing is retained).
+fn with_config<R>(rc: &RenderConfig, f: impl FnOnce(&ffi::RbConfig) -> R) -> R {
+    let uniforms = match &rc.uniforms {
+        Change::Keep      => ffi::RbField { change: ffi::RB_KEEP,   ptr: ptr::null(), count: 0 },
+        Change::Delete    => ffi::RbField { change: ffi::RB_DELETE, ptr: ptr::null(), count: 0 },
+        Change::Create(u) => ffi::RbField { change: ffi::RB_CREATE, ptr: u as *const _ as *const c_void, count: 1 },
+        Change::Update(u) => ffi::RbField { change: ffi::RB_UPDATE, ptr: u as *const _ as *const c_void, count: 1 },
+    };
+    let (tex_change, tex): (u32, Vec<ffi::RbTexture>) = match &rc.textures {
+        Change::Keep => (ffi::RB_KEEP, vec![]), Change::Delete => (ffi::RB_DELETE, vec![]),
+        Change::Create(t) | Change::Update(t) => (
+            if matches!(rc.textures, Change::Create(_)) { ffi::RB_CREATE } else { ffi::RB_UPDATE },
+            t.iter().map(|t| ffi::RbTexture { width: t.width, height: t.height, rgba_data: t.rgba_data.as_ptr() }).collect()),
+    };
+    let cfg = ffi::RbConfig {
+        uniforms, spheres: field(&rc.spheres), uvs: field(&rc.uvs), meshes: field(&rc.meshes),
+        lights: field(&rc.lights), bvh_nodes: field(&rc.bvh_nodes), bvh_indices: field(&rc.bvh_indices),
+        bvh_triangles: field(&rc.bvh_triangles),
+        textures: ffi::RbField { change: tex_change, ptr: tex.as_ptr() as *const c_void, count: tex.len() },
+    };
+    f(&cfg)
+}
+
+fn check(e: *mut ffi::RbEngine, rc: i32) -> Result<()> {
+    if rc == 0 { return Ok(()); }
+    let msg = unsafe { CStr::from_ptr(ffi::rb_last_error(e)) }.to_string_lossy().into_owned();
+    Err(anyhow!(msg))                      // e.g. "Invalid Spheres", "No more frames available"
+}
+
+fn frame_for(e: *mut ffi::RbEngine) -> Result<Frame> {
+    let (mut w, mut h) = (0u32, 0u32);
+    check(e, unsafe { ffi::rb_get_size(e, &mut w, &mut h) })?;
+    Ok(Frame::new(w as usize, h as usize, vec![0u8; w as usize * h as usize * 4]))
+}
+
+impl Engine {
+    pub fn new(rc: RenderConfig) -> Self {                       // engine-pathtracer lib.rs:111-119
+        let e = with_config(&rc, |c| unsafe { ffi::rb_create(c) });
+        assert!(!e.is_null(), "{}", unsafe { CStr::from_ptr(ffi::rb_last_error(ptr::null())) }.to_string_lossy());
+        Self { h: Arc::new(Mutex::new(Handle(e))) }
+    }
+}
+
+impl Renderer for Engine {
+    fn render(&mut self, rc: RenderConfig) -> Result<Frame> {   // lib.rs:58-71
+        let g = self.h.lock().unwrap();
+        check(g.0, with_config(&rc, |c| unsafe { ffi::rb_update(g.0, c) }))?;
+        let mut f = frame_for(g.0)?;
+        check(g.0, unsafe { ffi::rb_render(g.0, f.pixels.as_mut_ptr()) })?;
+        Ok(f)
+    }
+    fn frame_iterator(&mut self, rc: RenderConfig) -> Result<Box<dyn FrameIterator>> {   // lib.rs:86-96
+        let g = self.h.lock().unwrap();
+        check(g.0, with_config(&rc, |c| unsafe { ffi::rb_iter_begin(g.0, c) }))?;
+        Ok(Box::new(HipFrameIterator { h: Arc::clone(&self.h) }))
+    }
+}
+
+pub struct HipFrameIterator { h: Arc<Mutex<Handle>> }
+
+impl FrameIterator for HipFrameIterator {
+    fn has_next(&self) -> bool { unsafe { ffi::rb_iter_has_next(self.h.lock().unwrap().0) != 0 } }
+    fn next(&mut self) -> Result<Frame> {                        // lib.rs:169-228
+        let g = self.h.lock().unwrap();
+        let mut f = frame_for(g.0)?;
+        check(g.0, unsafe { ffi::rb_iter_next(g.0, f.pixels.as_mut_ptr()) })?;
+        Ok(f)
+    }
+    fn destroy(&mut self) { unsafe { ffi::rb_iter_destroy(self.h.lock().unwrap().0) } }
+}

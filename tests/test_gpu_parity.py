@@ -244,3 +244,18 @@ def test_largest_frame_of_the_baseline_configs():
     assert frame.pixels.shape == (4096, 4096, 4)
     assert np.all(frame.pixels.reshape(-1, 4) == np.array([147, 164, 181, 255], dtype=np.uint8))
     assert st["paths"] == 4096 * 4096
+
+
+@pytest.mark.parametrize("n,extent,camscale", [(20000, 100.0, 8.0), (50000, 30.0, 40.0), (5000, 400.0, 1.0)])
+def test_sphere_bvh_under_poor_conditioning(n, extent, camscale):
+    # far cameras / tiny spheres: the reference's discriminant is mostly rounding noise there, and the
+    # sphere tree must still return the linear scan's winner (here the GPU's own linear scan)
+    s = scenes.spheres_scene(n=n, width=160, height=160, spp=2, max_depth=5, extent=extent)
+    u = s.uniforms.copy()
+    u["camera"]["pos"] = np.array([0, 30, 120], np.float32) * np.float32(camscale)
+    u["camera"]["dir"] = -u["camera"]["pos"]
+    s = scenes.Scene(u, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices, s.bvh_triangles, s.uvs)
+    _, a, st = _hip(s, abi.KERNEL_STREAM, stats=False)
+    _, b, st2 = _hip(s, abi.KERNEL_STREAM, stats=False, no_sphere_bvh=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert st["segments"] == st2["segments"]

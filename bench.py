@@ -229,6 +229,16 @@ def main():
             roof["accumulate_ms_per_step"] = st["accumulate_ms"] / max(a.steps, 1)
             roof["note"] = ("algorithmic bytes / launch time; it can exceed the HBM peak because scene data is "
                             "served from the scalar cache / L1 / L2; `traffic` is what the PMC counters see in HBM")
+        # what actually bounds the trace kernel (VALU issue): PMC numbers of the same kernel on the
+        # same scene, collected by rocprofv3 in a separate profiled run (profiles/*_final_pmc.json)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_64spp_final_pmc.json")))["derived"]
+            if a.workload == "c2":
+                roof["valu"] = {"instr_per_64_segments": pmc["valu_instr_per_wave_iteration"],
+                                "lane_utilisation": pmc["valu_lane_utilisation"], "clock_GHz": pmc["clock_GHz"],
+                                "source": "profiles/r01_c2_64spp_final_pmc.json"}
+        except Exception:
+            pass
         tr = load_traffic(a.workload)
         if tr is not None:
             roof["traffic"] = tr.get("hbm_bytes_per_launch")

@@ -281,8 +281,11 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
 // that leaf's triangles (leaf phase); a lane whose stack is empty finishes its segment (spheres,
 // lights, shading) and starts the next segment or a new path at once, while the other lanes keep
 // walking.  Visit order per ray is unchanged, so the winner is the same triangle.
+#ifndef RB_BVH_WAVES
+#define RB_BVH_WAVES 1
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(kTraceBlock) k_trace_bvh(const KParams p) {
+__global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const KParams p) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;

@@ -115,6 +115,26 @@ def cpu_baseline(scene, budget_s):
             "sample": f"{sample}, {st['segments']} segments in {dt:.2f} s (oracle/rb_oracle.c, OpenMP)"}
 
 
+def measured_copy_bandwidth(device):
+    """On-box HBM ceiling: device-to-device copy of 1 GiB (read + write bytes per second)."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.zero_()
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    del a, b
+    return 2.0 * n * reps / dt / 1e9
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic_*.json), or None."""
     import glob
@@ -239,6 +259,10 @@ def main():
                                 "source": "profiles/r01_c2_64spp_final_pmc.json"}
         except Exception:
             pass
+        try:
+            roof["measured_copy_peak"] = measured_copy_bandwidth(f"cuda:{local_rank}")  # GB/s, read + write
+        except Exception:
+            pass
         tr = load_traffic(a.workload)
         if tr is not None:
             roof["traffic"] = tr.get("hbm_bytes_per_launch")
@@ -257,6 +281,7 @@ def main():
                        "parallelism": f"row-stripes x{world}" if world > 1 else "single GPU",
                        "stripe_rows": a.stripe_rows, "device": engine.device_name(local_rank)},
             "roofline": roof, "cpu_baseline": cpu,
+            "kernel_ms_per_step_median": sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else None,
         }
         if cpu:
             out["config"]["gpu_over_cpu"] = value / cpu["value"]

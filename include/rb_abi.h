@@ -215,7 +215,8 @@ typedef struct rb_options {
     uint32_t passes_per_launch; /* samples per pixel folded into one kernel launch; 0 = default */
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
-    uint32_t _reserved[5];      /* [0] persistent blocks per CU (0 = default), [1] colour-buffer budget in MiB (0 = 4096) */
+    uint32_t _reserved[5];      /* tuning / ablation knobs, 0 = default: [0] persistent blocks per CU, [1] colour-buffer
+                                   budget in MiB (4096), [2] queue batch, [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
 } rb_options;
 
 enum {

@@ -126,6 +126,7 @@ struct KParams {
     uint32_t blocks_per_cu;        // persistent grid density (0 = default)
     uint32_t queue_batch;          // items a wave reserves per global atomic (RB_KERNEL_STREAM)
     uint32_t no_leaf_stepping;     // RB_KERNEL_STREAM: 1 = per-segment traversal even for multi-node trees
+    uint32_t lds_mode;             // LDS staging of small meshes: 0 = when it fits, 1 = never
 };
 
 struct LaunchInfo {

@@ -28,7 +28,7 @@ constexpr uint32_t kPixelBlock = 256;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
-    extern __shared__ uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t tiles_x = (p.u.width + 15u) / 16u;
@@ -78,7 +78,7 @@ constexpr uint32_t kQueueBlock = 256;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
-    extern __shared__ uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];  // [stack_depth][blockDim.x]; empty for single-node trees
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t width = p.u.width;
@@ -178,7 +178,7 @@ constexpr uint32_t kTraceBlock = 256;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KParams p) {
-    extern __shared__ uint32_t s_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t width = p.u.width;
@@ -284,9 +284,14 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
 #ifndef RB_BVH_WAVES
 #define RB_BVH_WAVES 1
 #endif
-template <bool STATS>
-__global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const KParams p) {
-    extern __shared__ uint32_t s_stack[];
+// LDS = true: the whole tree (48 B per node) and the first 48 B of every prepared triangle are
+// first staged into LDS with coalesced 16-byte loads by the whole block, and the walk then reads
+// them with ds_read_b128 instead of going through L1/L2 -- for meshes small enough to fit next to
+// the traversal stacks: BLOCK = 1024, one block per CU, 16 waves share one staged copy of up to
+// 160 KiB (about 2 800 triangles).  1.2-1.6x the L1/L2 path on 160..2 700-triangle meshes.
+template <bool STATS, bool LDS, uint32_t BLOCK>
+__global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t width = p.u.width;
@@ -302,6 +307,27 @@ __global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const K
     const cf4p ptris = (cf4p)p.ptris;
     uint32_t* const stack = &s_stack[tid];
     Tally<STATS> tl;
+
+    v4f* const lds_nodes = reinterpret_cast<v4f*>(s_stack + p.stack_depth * BLOCK);
+    v4f* const lds_tris = lds_nodes + node_count * 3u;
+    if constexpr (LDS) {
+        const v4f* gn = reinterpret_cast<const v4f*>(p.nodes);
+        const v4f* gt = reinterpret_cast<const v4f*>(p.ptris);
+        for (uint32_t i = tid; i < node_count * 3u; i += BLOCK) lds_nodes[i] = gn[i];
+        for (uint32_t i = tid; i < p.index_len * 3u; i += BLOCK) {
+            const uint32_t slot = i / 3u, part = i - slot * 3u;
+            lds_tris[i] = gt[slot * 4u + part];
+        }
+        __syncthreads();
+    }
+    auto node_q = [&](uint32_t idx, uint32_t part) -> v4f {
+        if constexpr (LDS) return lds_nodes[idx * 3u + part];
+        else return nodes[idx * 3u + part];
+    };
+    auto tri_q = [&](uint32_t slot, uint32_t part) -> v4f {
+        if constexpr (LDS) return lds_tris[slot * 3u + part];
+        else return ptris[slot * 4u + part];
+    };
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
@@ -391,22 +417,23 @@ __global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const K
                 break;
             }
             sp--;
-            const uint32_t node_idx = stack[sp * kTraceBlock];
+            const uint32_t node_idx = stack[sp * BLOCK];
             if (node_idx >= node_count) continue;
-            const v4f n0 = nodes[node_idx * 3u], n1 = nodes[node_idx * 3u + 1u];
-            const v4u n2 = ((cu4p)p.nodes)[node_idx * 3u + 2u];
+            const v4f n0 = node_q(node_idx, 0u), n1 = node_q(node_idx, 1u), n2f = node_q(node_idx, 2u);
+            const uint32_t n_left = __float_as_uint(n2f.x), n_right = __float_as_uint(n2f.y),
+                           n_first = __float_as_uint(n2f.z), n_count = __float_as_uint(n2f.w);
             if constexpr (STATS) tl.nodes++;
             if (!isect_aabb(pt.o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
-            if (n2.w > 0u) {
-                first = n2.z;
-                count = n2.w;
+            if (n_count > 0u) {
+                first = n_first;
+                count = n_count;
             } else {
-                if (n2.x < node_count) {
-                    stack[sp * kTraceBlock] = n2.x;
+                if (n_left < node_count) {
+                    stack[sp * BLOCK] = n_left;
                     sp++;
                 }
-                if (n2.y < node_count) {
-                    stack[sp * kTraceBlock] = n2.y;
+                if (n_right < node_count) {
+                    stack[sp * BLOCK] = n_right;
                     sp++;
                 }
             }
@@ -419,15 +446,15 @@ __global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const K
             uint32_t slot = first;
 #if RB_TRI_PAIRS
             for (; slot + 2u <= end; slot += 2u) {
-                const v4f a0 = ptris[slot * 4u], b0 = ptris[slot * 4u + 1u], c0 = ptris[slot * 4u + 2u];
-                const v4f a1 = ptris[slot * 4u + 4u], b1 = ptris[slot * 4u + 5u], c1 = ptris[slot * 4u + 6u];
+                const v4f a0 = tri_q(slot, 0u), b0 = tri_q(slot, 1u), c0 = tri_q(slot, 2u);
+                const v4f a1 = tri_q(slot + 1u, 0u), b1 = tri_q(slot + 1u, 1u), c1 = tri_q(slot + 1u, 2u);
                 const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
                 if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
                 test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, pt.o, pt.d, th, tl);
             }
 #endif
             for (; slot < end; slot++) {
-                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+                const v4f a = tri_q(slot, 0u), b = tri_q(slot, 1u), c = tri_q(slot, 2u);
                 if (__float_as_uint(c.w) == 0u) continue;  // guard :336
                 if constexpr (STATS) tl.tris++;
                 const float before = th.t;
@@ -438,7 +465,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_BVH_WAVES) k_trace_bvh(const K
 
         // ---- (5) traversal complete: ground, spheres, lights, shading, next ray
         if (state == FINISH) {
-            const bool alive = segment_finish<STATS>(p, pt, th, stack, kTraceBlock, tl);
+            const bool alive = segment_finish<STATS>(p, pt, th, stack, BLOCK, tl);
             if (alive) {
                 state = BEGIN;
             } else {
@@ -660,12 +687,17 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
     } else {
         const uint64_t tiles = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u);
         const uint64_t items = tiles * 64u * p.n_passes * p.samples_per_pass;
-        li.grid = persistent_blocks(items, kTraceBlock, p.blocks_per_cu ? p.blocks_per_cu : 8u);
-        li.block = kTraceBlock;
+        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping && p.fast_nodes == nullptr;
+        // small meshes: stage the tree and the triangles' first 48 B in LDS next to the stacks, one
+        // 1024-thread block per CU (measured faster than three 256-thread blocks with their own copies)
+        const size_t scene_lds = (size_t)p.u.bvh_node_count * 48u + (size_t)p.index_len * 48u;
+        const bool lds_big = stepped && p.lds_mode != 1u && lds * 4u + scene_lds <= 160u * 1024u;
+        li.block = lds_big ? 1024u : kTraceBlock;
+        li.grid = persistent_blocks(items, li.block, lds_big ? 1u : (p.blocks_per_cu ? p.blocks_per_cu : 8u));
         if (li.grid == 0) return 0;
         // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64
         KParams q = p;
-        const uint64_t waves = (uint64_t)li.grid * (kTraceBlock / 64u);
+        const uint64_t waves = (uint64_t)li.grid * (li.block / 64u);
         uint64_t batch = items / (waves * 64u);
         batch = (batch / 64u) * 64u;
         if (batch < 64u) batch = 64u;
@@ -674,13 +706,22 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         q.queue_batch = (uint32_t)batch;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
-        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping && p.fast_nodes == nullptr;
-        li.kernel_name = stepped ? "k_trace_bvh" : "k_trace";
-        if (stepped) {
+        li.kernel_name = stepped ? (lds_big ? "k_trace_bvh_lds" : "k_trace_bvh") : "k_trace";
+        if (lds_big) {
+            li.lds_bytes = lds * 4u + scene_lds;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<true, true, 1024u>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<false, true, 1024u>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
             if (stats)
-                hipLaunchKernelGGL(k_trace_bvh<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
+                hipLaunchKernelGGL((k_trace_bvh<true, true, 1024u>), dim3(li.grid), dim3(1024), li.lds_bytes, stream, q);
             else
-                hipLaunchKernelGGL(k_trace_bvh<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+                hipLaunchKernelGGL((k_trace_bvh<false, true, 1024u>), dim3(li.grid), dim3(1024), li.lds_bytes, stream, q);
+        } else if (stepped) {
+            if (stats)
+                hipLaunchKernelGGL((k_trace_bvh<true, false, kTraceBlock>), dim3(li.grid), dim3(li.block), lds, stream, q);
+            else
+                hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), dim3(li.grid), dim3(li.block), lds, stream, q);
         } else if (stats) {
             hipLaunchKernelGGL(k_trace<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
         } else {

@@ -508,6 +508,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];
     p.no_leaf_stepping = e->opt._reserved[3];
+    p.lds_mode = e->opt._reserved[4];
     return p;
 }
 

@@ -61,6 +61,25 @@ def test_mesh_bvh_bit_exact(kernel):
     _assert_same(s, kernel)
 
 
+@pytest.mark.parametrize("grid,lds_mode,name", [(12, 0, "k_trace_bvh_lds"), (12, 1, "k_trace_bvh"),
+                                                (24, 0, "k_trace_bvh_lds"), (40, 0, "k_trace_bvh")])
+def test_leaf_stepped_walk_from_lds_and_from_l2(grid, lds_mode, name):
+    # meshes that fit in LDS next to the traversal stacks are staged there; larger ones, or
+    # lds_mode = 1, walk the same tree through L1/L2.  Same bits either way.
+    s = scenes.mesh_scene(grid, grid, 64, 40, 3, 5, seed=grid)
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc, stats=True, lds_mode=lds_mode)
+    frame = eng.render(rc)
+    acc, st = eng.read_accumulation(), eng.stats()
+    assert eng.last_kernel_name() == name
+    eng.close()
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32))
+    assert np.array_equal(frame.pixels, o_rgba)
+    for k in ("segments", "nodes_popped", "tris_tested", "mesh_hits"):
+        assert st[k] == o_st[k], k
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_sky_only_known_answer(kernel):
     s = scenes.sky_only()

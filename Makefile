@@ -8,7 +8,7 @@ OUT      := renderbaby_amd/librenderbaby_hip.so
 # Numerics contract: no FMA contraction, correctly rounded / and sqrt, no fast-math.
 NUMERICS := -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -Wall -Wno-unused-function
-SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp
+SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_build.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp
 HDRS     := $(CSRC)/rb_internal.hpp $(CSRC)/rb_device_common.hpp $(CSRC)/rb_device_math.hpp \
             $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp include/rb_abi.h
 

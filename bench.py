@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.achieved = null)")
     ap.add_argument("--fast-bvh", action="store_true", help="RB_FLAG_FAST_BVH (multi-node meshes; see DESIGN.md)")
+    ap.add_argument("--device-bvh", action="store_true", help="RB_FLAG_DEVICE_BVH: build the fast walk's tree on the GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --same-device) rehearses the N>1 path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -190,14 +191,14 @@ def main():
     # ---- instrumented pass (untimed): work counters for the algorithmic-bytes figure
     stats = None
     if not a.no_stats:
-        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True, fast_bvh=a.fast_bvh)
+        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True, fast_bvh=a.fast_bvh, device_bvh=a.device_bvh)
         r.engine.reset_stats()
         r.render_local()
         stats = r.engine.stats()
         r.close()
 
     r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel,
-                        host_gather=(a.backend != "nccl"), fast_bvh=a.fast_bvh)
+                        host_gather=(a.backend != "nccl"), fast_bvh=a.fast_bvh, device_bvh=a.device_bvh)
     for _ in range(a.warmup):
         r.step()
     r.engine.reset_stats()

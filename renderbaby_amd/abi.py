@@ -63,6 +63,7 @@ KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_QUEUE, KERNEL_STREAM = 0, 1, 2, 3
 FLAG_STATS = 1
 FLAG_NO_SPHERE_BVH = 2
 FLAG_FAST_BVH = 4
+FLAG_DEVICE_BVH = 8
 
 
 class Field(C.Structure):

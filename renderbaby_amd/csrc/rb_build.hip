@@ -1,0 +1,326 @@
+// rb_build.hip -- device-side build of the library's own triangle tree (RB_FLAG_DEVICE_BVH).
+//
+// the reference rebuilds its BVH on the CPU for every render
+// (scene_engine_adapter.rs:435-440, engine-bvh/src/bvh.rs:87-150).  The tree the opt-in fast walk
+// uses (rb_device_intersect.hpp, intersect_bvh_fast) can instead be built on the GPU from the
+// triangles that are already resident there:
+//
+//   k_lbvh_prims      tight box, |e1||e2| bound and centroid per triangle; mesh / centroid bounds
+//   k_lbvh_keys       30-bit Morton code of the centroid | item index  (unique 62-bit keys)
+//   rocprim radix sort of the keys
+//   k_lbvh_hierarchy  one thread per internal node: range and split from common key prefixes
+//                     (Karras, "Maximizing parallelism in the construction of BVHs", 2012)
+//   k_lbvh_refit      bottom-up: the second thread to reach a node merges its children's boxes
+//   k_lbvh_emit       64-B two-box nodes in the format of the host builder (rb_bvh.cpp); an
+//                     internal node over exactly two triangles becomes a two-triangle leaf
+//
+// The tree only steers the walk: which triangle wins, its t/u/v and all tie-breaking follow the
+// reference's tree and arithmetic (see intersect_bvh_fast), so frames are the same bits whichever
+// builder produced the tree.  A binned-SAH tree (host) is the better tree; this one is built in
+// milliseconds.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "rb_internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rb {
+namespace {
+
+constexpr uint32_t kLeafTag = 0x80000000u;
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// bounds[0..2] mesh min, [3..5] mesh max, [6..8] centroid min, [9..11] centroid max (ordered uints)
+__global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __restrict__ tris,
+                                                     const uint32_t* __restrict__ indices,
+                                                     const uint32_t* __restrict__ slots, uint32_t n,
+                                                     float4* __restrict__ pmin, float4* __restrict__ pmax,
+                                                     uint32_t* bounds) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const float inf = __builtin_inff();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    float cn[3] = {inf, inf, inf}, cx[3] = {-inf, -inf, -inf};
+    if (i < n) {
+        const rb_gpu_triangle t = tris[indices[slots[i]]];
+        double l1 = 0.0, l2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            l1 += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);
+            l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
+            mn[a] = fminf(t.v0[a], fminf(t.v1[a], t.v2[a]));
+            mx[a] = fmaxf(t.v0[a], fmaxf(t.v1[a], t.v2[a]));
+            cn[a] = cx[a] = 0.5f * (mn[a] + mx[a]);
+        }
+        // same bound as the host builder: largest |e1||e2| scales the per-ray box inflation
+        const float e1e2 = static_cast<float>(sqrt(l1) * sqrt(l2) * 1.0001);
+        pmin[i] = make_float4(mn[0], mn[1], mn[2], e1e2);
+        pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+            cn[a] = fminf(cn[a], __shfl_xor(cn[a], off, 64));
+            cx[a] = fmaxf(cx[a], __shfl_xor(cx[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bounds[a], f2ord(mn[a]));
+            atomicMax(&bounds[3 + a], f2ord(mx[a]));
+            atomicMin(&bounds[6 + a], f2ord(cn[a]));
+            atomicMax(&bounds[9 + a], f2ord(cx[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_keys(const float4* __restrict__ pmin, const float4* __restrict__ pmax,
+                                                    uint32_t n, const uint32_t* __restrict__ bounds,
+                                                    unsigned long long* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = pmin[i], b = pmax[i];
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ord2f(bounds[6 + k]), hi = ord2f(bounds[9 + k]);
+        const float ext = hi - lo;
+        float x = (ext > 0.0f) ? (c[k] - lo) / ext * 1024.0f : 0.0f;
+        x = fminf(fmaxf(x, 0.0f), 1023.0f);  // NaN -> 0
+        q[k] = static_cast<uint32_t>(x);
+    }
+    const uint32_t morton = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    keys[i] = (static_cast<unsigned long long>(morton) << 32) | i;
+}
+
+// Internal node i of the n-1 (Karras 2012, section 4).  Keys are unique, so the common-prefix
+// length delta() is always < 64.  Children: leaf `pos` is encoded as kLeafTag | pos.
+__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long* __restrict__ keys, uint32_t n,
+                                                         uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                         uint32_t* __restrict__ range_first,
+                                                         uint32_t* __restrict__ range_size,
+                                                         uint32_t* __restrict__ parent,
+                                                         uint32_t* __restrict__ leaf_parent) {
+    const int i = static_cast<int>(blockIdx.x * 256u + threadIdx.x);
+    const int last = static_cast<int>(n) - 1;
+    if (i >= last) return;
+    const unsigned long long ki = keys[i];
+    auto delta = [&](int j) -> int {
+        if (j < 0 || j > last) return -1;
+        return __clzll(static_cast<long long>(ki ^ keys[j]));
+    };
+    const int d = (delta(i + 1) - delta(i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(i - d);
+    int lmax = 2;
+    while (delta(i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    if (lo == gamma) {
+        left[i] = kLeafTag | static_cast<uint32_t>(gamma);
+        leaf_parent[gamma] = static_cast<uint32_t>(i);
+    } else {
+        left[i] = static_cast<uint32_t>(gamma);
+        parent[gamma] = static_cast<uint32_t>(i);
+    }
+    if (hi == gamma + 1) {
+        right[i] = kLeafTag | static_cast<uint32_t>(gamma + 1);
+        leaf_parent[gamma + 1] = static_cast<uint32_t>(i);
+    } else {
+        right[i] = static_cast<uint32_t>(gamma + 1);
+        parent[gamma + 1] = static_cast<uint32_t>(i);
+    }
+    range_first[i] = static_cast<uint32_t>(lo);
+    range_size[i] = static_cast<uint32_t>(hi - lo + 1);
+    if (i == 0) parent[0] = 0u;
+}
+
+// nmin[i] = {box min, largest |e1||e2| below}, nmax[i] = {box max, height as uint bits}.
+__global__ void __launch_bounds__(256) k_lbvh_refit(const unsigned long long* __restrict__ keys, uint32_t n,
+                                                     const float4* __restrict__ pmin, const float4* __restrict__ pmax,
+                                                     const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                     const uint32_t* __restrict__ range_size,
+                                                     const uint32_t* __restrict__ parent,
+                                                     const uint32_t* __restrict__ leaf_parent, uint32_t* flags,
+                                                     float4* nmin, float4* nmax) {
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= n) return;
+    uint32_t cur = leaf_parent[pos];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&flags[cur], 1u) == 0u) return;  // the sibling subtree is not finished yet
+        __threadfence();
+        float4 lo[2], hi[2];
+        uint32_t hgt[2];
+        const uint32_t ch[2] = {left[cur], right[cur]};
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] & kLeafTag) {
+                const uint32_t item = static_cast<uint32_t>(keys[ch[k] & ~kLeafTag]);
+                lo[k] = pmin[item];
+                hi[k] = pmax[item];
+                hgt[k] = 0u;
+            } else {
+                lo[k] = nmin[ch[k]];  // written by another CU: the fence above has invalidated L1
+                hi[k] = nmax[ch[k]];
+                hgt[k] = __float_as_uint(hi[k].w);
+            }
+        }
+        // a node over exactly two triangles is emitted as a leaf: it adds no level
+        const uint32_t h = (range_size[cur] == 2u) ? 0u : (hgt[0] > hgt[1] ? hgt[0] : hgt[1]) + 1u;
+        nmin[cur] = make_float4(fminf(lo[0].x, lo[1].x), fminf(lo[0].y, lo[1].y), fminf(lo[0].z, lo[1].z),
+                                fmaxf(lo[0].w, lo[1].w));
+        nmax[cur] = make_float4(fmaxf(hi[0].x, hi[1].x), fmaxf(hi[0].y, hi[1].y), fmaxf(hi[0].z, hi[1].z),
+                                __uint_as_float(h));
+        if (cur == 0u) return;
+        cur = parent[cur];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long* __restrict__ keys, uint32_t n,
+                                                    const uint32_t* __restrict__ slots,
+                                                    const float4* __restrict__ pmin, const float4* __restrict__ pmax,
+                                                    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                    const uint32_t* __restrict__ range_first,
+                                                    const uint32_t* __restrict__ range_size,
+                                                    const float4* __restrict__ nmin, const float4* __restrict__ nmax,
+                                                    const uint32_t* __restrict__ bounds, SphereNode* __restrict__ nodes,
+                                                    uint32_t* __restrict__ fast_slots, DeviceTreeInfo* info) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) fast_slots[i] = slots[static_cast<uint32_t>(keys[i])];
+    if (i + 1u < n) {
+        float4 o[4];
+        uint32_t ref[2];
+        const uint32_t ch[2] = {left[i], right[i]};
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] & kLeafTag) {
+                const uint32_t pos = ch[k] & ~kLeafTag;
+                const uint32_t item = static_cast<uint32_t>(keys[pos]);
+                o[2 * k] = pmin[item];
+                o[2 * k + 1] = pmax[item];
+                ref[k] = kLeafTag | pos;
+            } else {
+                o[2 * k] = nmin[ch[k]];
+                o[2 * k + 1] = nmax[ch[k]];
+                ref[k] = (range_size[ch[k]] == 2u) ? (kLeafTag | (1u << 28) | range_first[ch[k]]) : ch[k];
+            }
+        }
+        SphereNode nd;
+        nd.lmin[0] = o[0].x; nd.lmin[1] = o[0].y; nd.lmin[2] = o[0].z; nd.left = ref[0];
+        nd.lmax[0] = o[1].x; nd.lmax[1] = o[1].y; nd.lmax[2] = o[1].z; nd.right = ref[1];
+        nd.rmin[0] = o[2].x; nd.rmin[1] = o[2].y; nd.rmin[2] = o[2].z; nd._pad0 = __float_as_uint(o[0].w);
+        nd.rmax[0] = o[3].x; nd.rmax[1] = o[3].y; nd.rmax[2] = o[3].z; nd._pad1 = __float_as_uint(o[2].w);
+        nodes[i] = nd;
+    }
+    if (i == 0u) {
+        const float4 r0 = nmin[0], r1 = nmax[0];
+        info->root = (range_size[0] == 2u) ? (kLeafTag | (1u << 28)) : 0u;
+        info->depth = __float_as_uint(r1.w) + 2u;  // pending far children <= internal levels
+        info->root_amax = r0.w;
+        float d[3];
+        for (int a = 0; a < 3; ++a) {
+            info->bmin[a] = ord2f(bounds[a]);
+            info->bmax[a] = ord2f(bounds[3 + a]);
+            d[a] = info->bmax[a] - info->bmin[a];
+        }
+        info->margin = 1e-4f * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-6f;
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
+
+}  // namespace
+
+// All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).
+int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
+                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream_) {
+    if (n < 2u || n >= (1u << 28)) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using key_t = unsigned long long;
+    size_t sort_bytes = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<key_t*>(nullptr),
+                                            static_cast<key_t*>(nullptr), n, 0, 62, stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+    // one allocation, carved up
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    const size_t o_keys_in = carve(sizeof(key_t) * n), o_keys = carve(sizeof(key_t) * n);
+    const size_t o_pmin = carve(16u * n), o_pmax = carve(16u * n), o_nmin = carve(16u * n), o_nmax = carve(16u * n);
+    const size_t o_left = carve(4u * n), o_right = carve(4u * n), o_first = carve(4u * n), o_size = carve(4u * n);
+    const size_t o_parent = carve(4u * n), o_leafpar = carve(4u * n), o_flags = carve(4u * n);
+    const size_t o_bounds = carve(64), o_info = carve(sizeof(DeviceTreeInfo)), o_sort = carve(sort_bytes);
+    char* base = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&base), off);
+    if (e != hipSuccess) return static_cast<int>(e);
+    auto at = [&](size_t o) { return base + o; };
+    key_t* keys_in = reinterpret_cast<key_t*>(at(o_keys_in));
+    key_t* keys = reinterpret_cast<key_t*>(at(o_keys));
+    float4* pmin = reinterpret_cast<float4*>(at(o_pmin));
+    float4* pmax = reinterpret_cast<float4*>(at(o_pmax));
+    float4* nmin = reinterpret_cast<float4*>(at(o_nmin));
+    float4* nmax = reinterpret_cast<float4*>(at(o_nmax));
+    uint32_t* left = reinterpret_cast<uint32_t*>(at(o_left));
+    uint32_t* right = reinterpret_cast<uint32_t*>(at(o_right));
+    uint32_t* rfirst = reinterpret_cast<uint32_t*>(at(o_first));
+    uint32_t* rsize = reinterpret_cast<uint32_t*>(at(o_size));
+    uint32_t* parent = reinterpret_cast<uint32_t*>(at(o_parent));
+    uint32_t* leafpar = reinterpret_cast<uint32_t*>(at(o_leafpar));
+    uint32_t* flags = reinterpret_cast<uint32_t*>(at(o_flags));
+    uint32_t* bounds = reinterpret_cast<uint32_t*>(at(o_bounds));
+    DeviceTreeInfo* d_info = reinterpret_cast<DeviceTreeInfo*>(at(o_info));
+
+    const uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u,
+                               0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const dim3 grid((n + 255u) / 256u), block(256);
+    auto done = [&](hipError_t err) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(base);
+        return static_cast<int>(err);
+    };
+    e = hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return done(e);
+    e = hipMemsetAsync(flags, 0, 4u * n, stream);
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, n, pmin, pmax, bounds);
+    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, stream, pmin, pmax, n, bounds, keys_in);
+    e = rocprim::radix_sort_keys(at(o_sort), sort_bytes, keys_in, keys, n, 0, 62, stream);
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, stream, keys, n, left, right, rfirst, rsize, parent, leafpar);
+    hipLaunchKernelGGL(k_lbvh_refit, grid, block, 0, stream, keys, n, pmin, pmax, left, right, rsize, parent, leafpar,
+                       flags, nmin, nmax);
+    hipLaunchKernelGGL(k_lbvh_emit, grid, block, 0, stream, keys, n, slots, pmin, pmax, left, right, rfirst, rsize,
+                       nmin, nmax, bounds, nodes_out, fast_slots_out, d_info);
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(e);
+    e = hipMemcpyAsync(info_out, d_info, sizeof(DeviceTreeInfo), hipMemcpyDeviceToHost, stream);
+    return done(e);
+}
+
+}  // namespace rb

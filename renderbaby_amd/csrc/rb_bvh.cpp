@@ -369,8 +369,8 @@ struct FBuilder {
 };
 }  // namespace
 
-bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
-                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
+bool fast_bvh_prepare(uint32_t tri_count, const uint32_t* indices, uint32_t index_len, const rb_bvh_node* ref_nodes,
+                      uint32_t node_count, FastTree& out) {
     out = FastTree{};
     if (node_count == 0 || index_len == 0) return false;
     // ---- reference visit order (right child first, shader.wgsl:376-387) and per-slot metadata
@@ -399,6 +399,14 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
         }
     }
     if (slots.empty() || slots.size() >= (1u << 28)) return false;
+    out.slots = std::move(slots);
+    return true;
+}
+
+bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
+    if (!fast_bvh_prepare(tri_count, indices, index_len, ref_nodes, node_count, out)) return false;
+    const std::vector<uint32_t> slots = std::move(out.slots);
     // ---- tight boxes per item; items are indices into `slots`
     const size_t n = slots.size();
     std::vector<float> bmn(n * 3), bmx(n * 3), e1e2(n);

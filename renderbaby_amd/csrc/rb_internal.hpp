@@ -50,6 +50,19 @@ struct FastTree {
 };
 bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                     const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out);
+// The part of it that depends on the reference tree only: ref_parent, slot_meta, and `slots` = the
+// valid slots in the reference's visit order (the items a builder then arranges into a tree).
+bool fast_bvh_prepare(uint32_t tri_count, const uint32_t* indices, uint32_t index_len, const rb_bvh_node* ref_nodes,
+                      uint32_t node_count, FastTree& out);
+
+// ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
+struct DeviceTreeInfo {
+    uint32_t root, depth;
+    float margin, root_amax;
+    float bmin[3], bmax[3];
+};
+int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
+                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream);
 
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -96,6 +97,8 @@ struct rb_engine {
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
     bool fast_ready = false;
+    float fast_build_ms = 0.0f;
+    const char* fast_builder = "";  // which builder produced the fast tree ("host-sah" / "device-lbvh")
     std::vector<rb_gpu_triangle> host_tris;  // kept only when RB_FLAG_FAST_BVH is set
     std::vector<uint32_t> host_indices;
     DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
@@ -411,28 +414,66 @@ int ensure_prepared(rb_engine* e) {
     e->fast_ready = false;
     if ((e->opt.flags & RB_FLAG_FAST_BVH) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty()) {
         rb::FastTree ft;
-        if (rb::fast_bvh_build(e->host_tris.data(), static_cast<uint32_t>(e->host_tris.size()), e->host_indices.data(),
-                               static_cast<uint32_t>(e->host_indices.size()), e->host_nodes.data(),
-                               static_cast<uint32_t>(e->host_nodes.size()), rb::kStackDepth, ft)) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        const uint32_t n_tris = static_cast<uint32_t>(e->host_tris.size()), n_idx = static_cast<uint32_t>(e->host_indices.size());
+        const uint32_t n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+        bool built = false;
+        e->fast_builder = "";
+        if (e->opt.flags & RB_FLAG_DEVICE_BVH) {
+            // reference-order metadata on the host (one pass over the caller's tree), the tree on the device
+            if (rb::fast_bvh_prepare(n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft) &&
+                ft.slots.size() >= 1024) {
+                const uint32_t n = static_cast<uint32_t>(ft.slots.size());
+                DevBuf<uint32_t> visit_slots;
+                rc = upload(e, visit_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
+                if (rc) return rc;
+                HIP_TRY(e, e->fast_nodes.resize(n - 1));
+                HIP_TRY(e, e->fast_slots.resize(n));
+                rb::DeviceTreeInfo info{};
+                rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
+                                               e->fast_slots.ptr, &info, e->stream);
+                if (rc) return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+                if (info.depth <= rb::kStackDepth) {
+                    ft.root = info.root;
+                    ft.depth = info.depth;
+                    ft.margin = info.margin;
+                    ft.root_amax = info.root_amax;
+                    for (int i = 0; i < 3; ++i) {
+                        ft.bmin[i] = info.bmin[i];
+                        ft.bmax[i] = info.bmax[i];
+                    }
+                    built = true;
+                    e->fast_builder = "device-lbvh";
+                }  // else: deeper than the LDS stack -- use the depth-limited host builder
+            }
+        }
+        if (!built) {
+            if (!rb::fast_bvh_build(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes,
+                                    rb::kStackDepth, ft))
+                return RB_OK;  // keep the exact walk
             rc = upload(e, e->fast_nodes, ft.nodes.data(), ft.nodes.size(), nullptr, true);
             if (!rc) rc = upload(e, e->fast_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
-            if (!rc) rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
-            if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
             if (rc) return rc;
-            HIP_TRY(e, e->fast_tris.resize(ft.slots.size()));
-            rc = rb::launch_gather_tris(e->ptris.ptr, e->fast_slots.ptr, static_cast<uint32_t>(ft.slots.size()), e->fast_tris.ptr, e->stream);
-            if (rc) return fail(e, RB_ERR_DEVICE, "gather kernel launch failed");
-            HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ft` is a local
-            e->fast_root = ft.root;
-            e->fast_depth = ft.depth;
-            e->fast_margin = ft.margin;
-            e->fast_root_amax = ft.root_amax;
-            for (int i = 0; i < 3; ++i) {
-                e->fast_bmin[i] = ft.bmin[i];
-                e->fast_bmax[i] = ft.bmax[i];
-            }
-            e->fast_ready = true;
+            e->fast_builder = "host-sah";
         }
+        rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
+        if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
+        if (rc) return rc;
+        const size_t n_items = e->fast_slots.count;
+        HIP_TRY(e, e->fast_tris.resize(n_items));
+        rc = rb::launch_gather_tris(e->ptris.ptr, e->fast_slots.ptr, static_cast<uint32_t>(n_items), e->fast_tris.ptr, e->stream);
+        if (rc) return fail(e, RB_ERR_DEVICE, "gather kernel launch failed");
+        HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ft` is a local
+        e->fast_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        e->fast_root = ft.root;
+        e->fast_depth = ft.depth;
+        e->fast_margin = ft.margin;
+        e->fast_root_amax = ft.root_amax;
+        for (int i = 0; i < 3; ++i) {
+            e->fast_bmin[i] = ft.bmin[i];
+            e->fast_bmax[i] = ft.bmax[i];
+        }
+        e->fast_ready = true;
     }
     return RB_OK;
 }
@@ -975,6 +1016,11 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris, rb_bvh_node* nodes_
 const char* rb_version(void) { return "renderbaby-hip 0.1 (gfx950)"; }
 
 const char* rb_last_kernel_name(const rb_engine* e) { return e ? e->last_kernel_name : ""; }
+
+const char* rb_fast_bvh_builder(const rb_engine* e, float* build_ms) {
+    if (build_ms) *build_ms = e ? e->fast_build_ms : 0.0f;
+    return (e && e->fast_ready) ? e->fast_builder : "";
+}
 
 int rb_device_name(int device, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0) return RB_ERR_NULL_ARGUMENT;

@@ -63,7 +63,7 @@ class ShardedRenderer:
     [H, W, 4] uint8 tensor there, None elsewhere)."""
 
     def __init__(self, scene, rank=0, world=1, device=0, stripe_rows=DEFAULT_STRIPE_ROWS, kernel=0,
-                 passes_per_launch=0, stats=False, host_gather=False, fast_bvh=False):
+                 passes_per_launch=0, stats=False, host_gather=False, fast_bvh=False, device_bvh=False):
         import torch
         from .engine import Engine, RenderConfig
         self.torch = torch
@@ -72,7 +72,8 @@ class ShardedRenderer:
         self.host_gather = host_gather  # gloo rehearsal: gather CPU copies instead of device memory
         rc = RenderConfig.from_scene(scene)
         self.engine = Engine.new(rc, device=device, shard_rank=rank, shard_count=world, stripe_rows=stripe_rows,
-                                 kernel=kernel, passes_per_launch=passes_per_launch, stats=stats, fast_bvh=fast_bvh)
+                                 kernel=kernel, passes_per_launch=passes_per_launch, stats=stats, fast_bvh=fast_bvh,
+                                 device_bvh=device_bvh)
         self.engine.update(rc)
         self.width, self.height = scene.width, scene.height
         self.owned, self.padded = shard_layout(self.height, rank, world, stripe_rows)

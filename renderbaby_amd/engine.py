@@ -169,7 +169,7 @@ class Engine:
     """``engine_pathtracer::Engine`` for the HIP backend."""
 
     def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
-                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0):
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False):
         self._lib = load()
         cfg, keep = rc.to_c()
         opt = abi.Options()
@@ -178,7 +178,7 @@ class Engine:
         opt.passes_per_launch = passes_per_launch
         opt.kernel = kernel
         opt.flags = (abi.FLAG_STATS if stats else 0) | (abi.FLAG_NO_SPHERE_BVH if no_sphere_bvh else 0) \
-            | (abi.FLAG_FAST_BVH if fast_bvh else 0)
+            | (abi.FLAG_FAST_BVH if (fast_bvh or device_bvh) else 0) | (abi.FLAG_DEVICE_BVH if device_bvh else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[4] = int(lds_mode)   # LDS staging of small meshes: 0 = when it fits, 1 = never
@@ -287,6 +287,12 @@ class Engine:
 
     def last_kernel_name(self):
         return (self._lib.rb_last_kernel_name(self._h) or b"").decode()
+
+    def fast_bvh_builder(self):
+        """("host-sah" | "device-lbvh" | "", build milliseconds) of the tree RB_FLAG_FAST_BVH walks."""
+        ms = C.c_float()
+        name = (self._lib.rb_fast_bvh_builder(self._h, C.byref(ms)) or b"").decode()
+        return name, ms.value
 
     def last_dispatch_ms(self):
         ms = C.c_float()

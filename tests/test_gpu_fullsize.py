@@ -70,16 +70,18 @@ def test_c3_mesh_subrectangle_matches_oracle():
 
 
 def test_c3_fast_bvh_equals_reference_walk_on_the_full_frame():
-    # 16.6 M paths / 28.8 M segments through the 50 176-triangle mesh: the opt-in fast walk
-    # must not change a single bit of the frame
+    # 16.6 M paths / 28.8 M segments through the 50 176-triangle mesh: the opt-in fast walk,
+    # over the host-built or the device-built tree, must not change a single bit of the frame
     s = scenes.mesh_scene(112, 112, 1920, 1080, 8, 5)
     rc = RenderConfig.from_scene(s)
     out = {}
-    for fast in (False, True):
-        e = Engine.new(rc, fast_bvh=fast)
+    for mode in ("exact", "host-sah", "device-lbvh"):
+        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-lbvh"))
         e.render(rc)
-        out[fast] = (e.read_accumulation(), e.stats()["segments"])
+        out[mode] = (e.read_accumulation(), e.stats()["segments"])
+        assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
         e.close()
-    diff = (out[False][0].view(np.uint32) != out[True][0].view(np.uint32)).any(axis=-1)
-    assert diff.sum() == 0, f"{int(diff.sum())} of {diff.size} pixels differ"
-    assert out[False][1] == out[True][1]
+    for mode in ("host-sah", "device-lbvh"):
+        diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
+        assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
+        assert out["exact"][1] == out[mode][1]

@@ -200,6 +200,28 @@ def test_fast_bvh_reproduces_the_reference_walk(grid, w, h, spp, color_hash):
     assert st["tris_tested"] < o_st["tris_tested"] / 4  # it must actually be the fast walk
 
 
+@pytest.mark.parametrize("grid,w,h,spp,builder", [(24, 64, 40, 4, "device-lbvh"), (112, 96, 54, 2, "device-lbvh"),
+                                                  (12, 64, 40, 2, "host-sah")])
+def test_device_built_tree_reproduces_the_reference_walk(grid, w, h, spp, builder):
+    # RB_FLAG_DEVICE_BVH: the fast walk's tree built on the GPU (Morton order + LBVH).  The tree only
+    # steers the walk, so the frame is still the reference walk's, bit for bit.  Below 1024 triangles
+    # the host builder is used.
+    s = scenes.mesh_scene(grid, grid, w, h, spp, 5, seed=7)
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc, stats=True, device_bvh=True)
+    frame = eng.render(rc)
+    acc, st = eng.read_accumulation(), eng.stats()
+    name, ms = eng.fast_bvh_builder()
+    eng.close()
+    assert name == builder and ms > 0.0
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    bad = np.argwhere(acc.view(np.uint32) != o_acc.view(np.uint32))
+    assert len(bad) == 0, (len(bad), bad[:4])
+    assert np.array_equal(frame.pixels, o_rgba)
+    assert st["segments"] == o_st["segments"]
+    assert st["tris_tested"] < o_st["tris_tested"] / 4
+
+
 def test_fast_reciprocal_and_sqrt_are_exhaustively_exact():
     # the kernels replace the 12-instruction IEEE divide by rcp + Newton/FMA steps where the
     # operands allow; correctness is a property of the significand, so it is checked for ALL

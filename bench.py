@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "lamp"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--stripe-rows", type=int, default=1)
@@ -65,6 +65,11 @@ def make_scene(name, spp):
     elif name == "c4":
         s = scenes.spheres_scene()
         desc = "C4 1M random spheres over a checkerboard ground, 4096x4096, 64 spp, 5 bounces"
+    elif name == "lamp":
+        from tests import _refscenes   # data of the reference's own largest fixture scene (tests/golden/ref_fixtures)
+        s = _refscenes.ref_lamp()
+        desc = ("reference fixture final_cornell_with_lamp_and_spheres.rscn: 68768 tris, 4 spheres, ground, "
+                "2056x2056, 512 spp, 5 bounces")
     else:
         s = scenes.mesh_c5()
         desc = "C5 procedural 1048576-tri mesh + light quad, BVH leaf<=128, 3840x2160, 4096 spp, 16 bounces"

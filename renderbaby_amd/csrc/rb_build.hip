@@ -6,8 +6,8 @@
 // triangles that are already resident there:
 //
 //   k_lbvh_prims      tight box, |e1||e2| bound and centroid per triangle; mesh / centroid bounds
-//   k_lbvh_keys       30-bit Morton code of the centroid | item index  (unique 62-bit keys)
-//   rocprim radix sort of the keys
+//   k_lbvh_keys       63-bit Morton code of the centroid (21 bits per axis)
+//   rocprim radix sort of (key, item) pairs; equal keys are told apart by their sorted position
 //   k_lbvh_hierarchy  one thread per internal node: range and split from common key prefixes
 //                     (Karras, "Maximizing parallelism in the construction of BVHs", 2012)
 //   k_lbvh_refit      bottom-up: the second thread to reach a node merges its children's boxes
@@ -84,17 +84,19 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __res
     }
 }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
+__device__ __forceinline__ unsigned long long spread21(uint32_t x) {  // 21 bits -> every third bit
+    unsigned long long v = x & 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
 __global__ void __launch_bounds__(256) k_lbvh_keys(const float4* __restrict__ pmin, const float4* __restrict__ pmax,
                                                     uint32_t n, const uint32_t* __restrict__ bounds,
-                                                    unsigned long long* __restrict__ keys) {
+                                                    unsigned long long* __restrict__ keys, uint32_t* __restrict__ items) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 a = pmin[i], b = pmax[i];
@@ -103,16 +105,17 @@ __global__ void __launch_bounds__(256) k_lbvh_keys(const float4* __restrict__ pm
     for (int k = 0; k < 3; ++k) {
         const float lo = ord2f(bounds[6 + k]), hi = ord2f(bounds[9 + k]);
         const float ext = hi - lo;
-        float x = (ext > 0.0f) ? (c[k] - lo) / ext * 1024.0f : 0.0f;
-        x = fminf(fmaxf(x, 0.0f), 1023.0f);  // NaN -> 0
+        float x = (ext > 0.0f) ? (c[k] - lo) / ext * 2097152.0f : 0.0f;
+        x = fminf(fmaxf(x, 0.0f), 2097151.0f);  // NaN -> 0
         q[k] = static_cast<uint32_t>(x);
     }
-    const uint32_t morton = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
-    keys[i] = (static_cast<unsigned long long>(morton) << 32) | i;
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    items[i] = i;
 }
 
-// Internal node i of the n-1 (Karras 2012, section 4).  Keys are unique, so the common-prefix
-// length delta() is always < 64.  Children: leaf `pos` is encoded as kLeafTag | pos.
+// Internal node i of the n-1 (Karras 2012, section 4).  Equal keys are extended by their sorted
+// position, as in the paper, so a run of k identical codes becomes a subtree of depth ~log2 k.
+// Children: leaf `pos` is encoded as kLeafTag | pos.
 __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long* __restrict__ keys, uint32_t n,
                                                          uint32_t* __restrict__ left, uint32_t* __restrict__ right,
                                                          uint32_t* __restrict__ range_first,
@@ -125,7 +128,8 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long
     const unsigned long long ki = keys[i];
     auto delta = [&](int j) -> int {
         if (j < 0 || j > last) return -1;
-        return __clzll(static_cast<long long>(ki ^ keys[j]));
+        const unsigned long long x = ki ^ keys[j];
+        return x ? __clzll(static_cast<long long>(x)) : 64 + __clz(i ^ j);
     };
     const int d = (delta(i + 1) - delta(i - 1)) >= 0 ? 1 : -1;
     const int dmin = delta(i - d);
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long
 }
 
 // nmin[i] = {box min, largest |e1||e2| below}, nmax[i] = {box max, height as uint bits}.
-__global__ void __launch_bounds__(256) k_lbvh_refit(const unsigned long long* __restrict__ keys, uint32_t n,
+__global__ void __launch_bounds__(256) k_lbvh_refit(const uint32_t* __restrict__ items, uint32_t n,
                                                      const float4* __restrict__ pmin, const float4* __restrict__ pmax,
                                                      const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                      const uint32_t* __restrict__ range_size,
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const unsigned long long* __
         const uint32_t ch[2] = {left[cur], right[cur]};
         for (int k = 0; k < 2; ++k) {
             if (ch[k] & kLeafTag) {
-                const uint32_t item = static_cast<uint32_t>(keys[ch[k] & ~kLeafTag]);
+                const uint32_t item = items[ch[k] & ~kLeafTag];
                 lo[k] = pmin[item];
                 hi[k] = pmax[item];
                 hgt[k] = 0u;
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const unsigned long long* __
     }
 }
 
-__global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long* __restrict__ keys, uint32_t n,
+__global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ items, uint32_t n,
                                                     const uint32_t* __restrict__ slots,
                                                     const float4* __restrict__ pmin, const float4* __restrict__ pmax,
                                                     const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long* __r
                                                     const uint32_t* __restrict__ bounds, SphereNode* __restrict__ nodes,
                                                     uint32_t* __restrict__ fast_slots, DeviceTreeInfo* info) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) fast_slots[i] = slots[static_cast<uint32_t>(keys[i])];
+    if (i < n) fast_slots[i] = slots[items[i]];
     if (i + 1u < n) {
         float4 o[4];
         uint32_t ref[2];
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long* __r
         for (int k = 0; k < 2; ++k) {
             if (ch[k] & kLeafTag) {
                 const uint32_t pos = ch[k] & ~kLeafTag;
-                const uint32_t item = static_cast<uint32_t>(keys[pos]);
+                const uint32_t item = items[pos];
                 o[2 * k] = pmin[item];
                 o[2 * k + 1] = pmax[item];
                 ref[k] = kLeafTag | pos;
@@ -265,13 +269,15 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using key_t = unsigned long long;
     size_t sort_bytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<key_t*>(nullptr),
-                                            static_cast<key_t*>(nullptr), n, 0, 62, stream);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<key_t*>(nullptr), static_cast<key_t*>(nullptr),
+                                             static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n, 0, 63,
+                                             stream);
     if (e != hipSuccess) return static_cast<int>(e);
     // one allocation, carved up
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
     const size_t o_keys_in = carve(sizeof(key_t) * n), o_keys = carve(sizeof(key_t) * n);
+    const size_t o_items_in = carve(4u * n), o_items = carve(4u * n);
     const size_t o_pmin = carve(16u * n), o_pmax = carve(16u * n), o_nmin = carve(16u * n), o_nmax = carve(16u * n);
     const size_t o_left = carve(4u * n), o_right = carve(4u * n), o_first = carve(4u * n), o_size = carve(4u * n);
     const size_t o_parent = carve(4u * n), o_leafpar = carve(4u * n), o_flags = carve(4u * n);
@@ -282,6 +288,8 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     auto at = [&](size_t o) { return base + o; };
     key_t* keys_in = reinterpret_cast<key_t*>(at(o_keys_in));
     key_t* keys = reinterpret_cast<key_t*>(at(o_keys));
+    uint32_t* items_in = reinterpret_cast<uint32_t*>(at(o_items_in));
+    uint32_t* items = reinterpret_cast<uint32_t*>(at(o_items));
     float4* pmin = reinterpret_cast<float4*>(at(o_pmin));
     float4* pmax = reinterpret_cast<float4*>(at(o_pmax));
     float4* nmin = reinterpret_cast<float4*>(at(o_nmin));
@@ -309,13 +317,13 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     e = hipMemsetAsync(flags, 0, 4u * n, stream);
     if (e != hipSuccess) return done(e);
     hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, n, pmin, pmax, bounds);
-    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, stream, pmin, pmax, n, bounds, keys_in);
-    e = rocprim::radix_sort_keys(at(o_sort), sort_bytes, keys_in, keys, n, 0, 62, stream);
+    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, stream, pmin, pmax, n, bounds, keys_in, items_in);
+    e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_in, keys, items_in, items, n, 0, 63, stream);
     if (e != hipSuccess) return done(e);
     hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, stream, keys, n, left, right, rfirst, rsize, parent, leafpar);
-    hipLaunchKernelGGL(k_lbvh_refit, grid, block, 0, stream, keys, n, pmin, pmax, left, right, rsize, parent, leafpar,
+    hipLaunchKernelGGL(k_lbvh_refit, grid, block, 0, stream, items, n, pmin, pmax, left, right, rsize, parent, leafpar,
                        flags, nmin, nmax);
-    hipLaunchKernelGGL(k_lbvh_emit, grid, block, 0, stream, keys, n, slots, pmin, pmax, left, right, rfirst, rsize,
+    hipLaunchKernelGGL(k_lbvh_emit, grid, block, 0, stream, items, n, slots, pmin, pmax, left, right, rfirst, rsize,
                        nmin, nmax, bounds, nodes_out, fast_slots_out, d_info);
     e = hipGetLastError();
     if (e != hipSuccess) return done(e);

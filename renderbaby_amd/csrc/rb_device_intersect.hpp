@@ -318,6 +318,17 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
         }
     };
 
+    // Entries beyond the LDS stack (trees deeper than kStackDepth: only device-built ones, the host
+    // builder limits its depth) spill to this lane's column of a global scratch array.
+    uint32_t* const ovf = p.stack_overflow + (blockIdx.x * blockDim.x + threadIdx.x);
+    const uint32_t ovf_stride = gridDim.x * blockDim.x;
+    auto push = [&](int at, uint32_t v) {
+        if (at < (int)kStackDepth) stack[at * stride] = v;
+        else ovf[(uint32_t)(at - (int)kStackDepth) * ovf_stride] = v;
+    };
+    auto pop = [&](int at) -> uint32_t {
+        return (at < (int)kStackDepth) ? stack[at * stride] : ovf[(uint32_t)(at - (int)kStackDepth) * ovf_stride];
+    };
     uint32_t cur = p.fast_root;
     int sp = 0;
     for (;;) {
@@ -325,7 +336,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
             leaf(cur);
             if (sp == 0) break;
             sp--;
-            cur = stack[sp * stride];
+            cur = pop(sp);
             continue;
         }
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
@@ -335,7 +346,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
         const bool hl = entry(l0, l1, r0.w, tl_), hr = entry(r0, r1, r1.w, tr_);
         if (hl && hr) {
             const bool left_first = !(tr_ < tl_);
-            stack[sp * stride] = left_first ? rref : lref;
+            push(sp, left_first ? rref : lref);
             sp++;
             cur = left_first ? lref : rref;
         } else if (hl) {
@@ -345,7 +356,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
         } else {
             if (sp == 0) break;
             sp--;
-            cur = stack[sp * stride];
+            cur = pop(sp);
         }
     }
     return h;

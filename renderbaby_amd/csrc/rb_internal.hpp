@@ -140,6 +140,7 @@ struct KParams {
     uint32_t queue_batch;          // items a wave reserves per global atomic (RB_KERNEL_STREAM)
     uint32_t no_leaf_stepping;     // RB_KERNEL_STREAM: 1 = per-segment traversal even for multi-node trees
     uint32_t lds_mode;             // LDS staging of small meshes: 0 = when it fits, 1 = never
+    uint32_t* stack_overflow;      // fast walk: entries beyond kStackDepth, [entry][grid * block] (nullptr if never needed)
 };
 
 struct LaunchInfo {
@@ -161,5 +162,6 @@ int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint3
 int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch16, void* stream);
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);
 int device_cu_count(int device);
+uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu);  // upper bound of grid * block of the stream kernels
 
 }  // namespace rb

@@ -657,6 +657,12 @@ static uint32_t persistent_blocks(uint64_t items, uint32_t block, uint32_t block
     return blocks;
 }
 
+uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (uint32_t)device_cu_count(dev) * (blocks_per_cu ? blocks_per_cu : 8u) * 256u;  // k_trace / k_queue blocks are <= 256 threads
+}
+
 int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info, void* ev_after_trace) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LaunchInfo li{};

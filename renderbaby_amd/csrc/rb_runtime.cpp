@@ -92,7 +92,7 @@ struct rb_engine {
     DevBuf<uint32_t> queue;
     DevBuf<rb::SphereNode> fast_nodes; // opt-in fast triangle tree (RB_FLAG_FAST_BVH)
     DevBuf<rb::PrepTri> fast_tris;
-    DevBuf<uint32_t> fast_slots, slot_meta, ref_parent;
+    DevBuf<uint32_t> fast_slots, slot_meta, ref_parent, stack_overflow;
     uint32_t fast_root = 0, fast_depth = 0;
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
@@ -433,7 +433,16 @@ int ensure_prepared(rb_engine* e) {
                 rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
                                                e->fast_slots.ptr, &info, e->stream);
                 if (rc) return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
-                if (info.depth <= rb::kStackDepth) {
+                // a tree deeper than the LDS stack spills to a global scratch column per lane, which only the
+                // persistent kernels (bounded grid) get; otherwise use the depth-limited host builder
+                const uint32_t kern = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
+                bool usable = info.depth <= rb::kStackDepth;
+                if (!usable && kern != RB_KERNEL_PIXEL && info.depth <= 128u) {
+                    const size_t lanes = rb::stream_kernel_max_threads(e->opt._reserved[0]);
+                    HIP_TRY(e, e->stack_overflow.resize(lanes * (info.depth - rb::kStackDepth)));
+                    usable = true;
+                }
+                if (usable) {
                     ft.root = info.root;
                     ft.depth = info.depth;
                     ft.margin = info.margin;
@@ -444,7 +453,7 @@ int ensure_prepared(rb_engine* e) {
                     }
                     built = true;
                     e->fast_builder = "device-lbvh";
-                }  // else: deeper than the LDS stack -- use the depth-limited host builder
+                }
             }
         }
         if (!built) {
@@ -545,7 +554,8 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     // a single-node tree is walked without a stack (rb_kernels.hip, intersect_bvh)
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
     if (use_sph_bvh) p.stack_depth = std::max(p.stack_depth, e->sph_depth);
-    if (use_fast) p.stack_depth = std::max(p.stack_depth, e->fast_depth);
+    if (use_fast) p.stack_depth = std::max(p.stack_depth, std::min(e->fast_depth, rb::kStackDepth));
+    p.stack_overflow = e->stack_overflow.ptr;
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];
     p.no_leaf_stepping = e->opt._reserved[3];

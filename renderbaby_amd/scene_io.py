@@ -194,3 +194,283 @@ def point_light(position, luminosity, color):
     l["material"] = scenes.material(diffuse=(0, 0, 0), specular=(0, 0, 0), shininess=0.0,
                                     emissive=np.asarray(color, np.float32) * np.float32(luminosity), illum=0)
     return l
+
+
+# ---------------------------------------------------------------------------------------------
+# Scene files (.json / .rscn), mesh transforms, textures, PNG out -- SURVEY 8(f) rows 3 and 4.
+# ---------------------------------------------------------------------------------------------
+import io
+import json
+import os
+import zipfile
+
+# MaterialPresets -> Material (crates/scene-objects/src/material.rs:123-172); Material::default()
+# is the Mirror preset (:67-80).
+PRESETS = {
+    "plastic": ObjMaterial("plastic", [0.0] * 3, [1.0] * 3, [0.0] * 3, [0.0] * 3, 1.0, 0.0, 2),
+    "light": ObjMaterial("light", [0.0] * 3, [0.0] * 3, [0.0] * 3, [100.0] * 3, 1.0, 0.0, 2),
+    "mirror": ObjMaterial("mirror", [0.0] * 3, [0.0] * 3, [1.0] * 3, [0.0] * 3, 0.0, 1000.0, 2),
+    "metal": ObjMaterial("metal", [0.0] * 3, [0.0] * 3, [0.5] * 3, [0.0] * 3, 1.0, 500.0, 2),
+}
+DEFAULT_PRESET = "mirror"
+
+
+class SceneFileError(ValueError):
+    """The file does not comply with the scene schema (scene_importer.rs:198-228)."""
+
+
+def preset_material(name: str) -> ObjMaterial:
+    """MaterialPresets::try_from, falling back to Material::default() (scene_importer.rs:101-107)."""
+    return PRESETS.get(name, PRESETS[DEFAULT_PRESET])
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _centroid(v: np.ndarray) -> np.ndarray:
+    # Mesh::calculate_centroid (mesh.rs:146-166): sequential f32 sums, then / n
+    s = np.zeros(3, np.float32)
+    for p in v:
+        s = (s + p).astype(np.float32)
+    return (s / np.float32(len(v))).astype(np.float32)
+
+
+def euler_zyx(rotation_deg) -> np.ndarray:
+    """Mat3::from_euler(EulerRot::ZYX, yaw = z, pitch = y, roll = x) = Rz * Ry * Rx, angles in
+    degrees (mesh.rs:229-237; x = roll, y = pitch, z = yaw per scene_io_objects.rs:35)."""
+    rx, ry, rz = (np.deg2rad(np.float32(a)).astype(np.float32) for a in rotation_deg)
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], np.float32)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float32)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], np.float32)
+    return (Rz @ Ry @ Rx).astype(np.float32)
+
+
+def transform_mesh(mesh: SceneMesh, scale=1.0, rotation=(0.0, 0.0, 0.0), translation=(0.0, 0.0, 0.0)) -> SceneMesh:
+    """load_object_from_file_relative (render_scene.rs:146-160): uniform scale about the centroid by
+    scale.x (mesh.rs:200-213), ZYX Euler rotation about the centroid (mesh.rs:104-123,229-248), then
+    translation (mesh.rs:217-225).  f32 throughout."""
+    v = mesh.vertices.astype(np.float32).copy()
+    if len(v) == 0:
+        return mesh
+    c = _centroid(v)
+    v = (c + (v - c) * np.float32(scale)).astype(np.float32)
+    c = _centroid(v)
+    R = euler_zyx(rotation)
+    v = ((v - c) @ R.T + c).astype(np.float32)
+    v = (v + _f32(translation)).astype(np.float32)
+    return SceneMesh(v, mesh.uvs, mesh.material_index, mesh.materials)
+
+
+def load_texture(path: str):
+    """TextureCache::load (texture_loader.rs:28-50): RGBA8, u32 = little-endian bytes (R low)."""
+    from PIL import Image
+    img = Image.open(path).convert("RGBA")
+    a = np.asarray(img, dtype=np.uint8)
+    return a.shape[1], a.shape[0], np.ascontiguousarray(a).view(np.uint32).reshape(-1).copy()
+
+
+def load_obj_file(path: str, texture_paths: Optional[set] = None) -> SceneMesh:
+    """load_obj (obj_parser.rs:143-252): the OBJ, every readable mtllib next to it, and the
+    materials' map_Kd paths (relative to the MTL's directory) collected into ``texture_paths``."""
+    with open(path, "r", errors="replace") as f:
+        obj = parse_obj(f.read())
+    parent = os.path.dirname(os.path.abspath(path))
+    materials: List[ObjMaterial] = []
+    for rel in obj.mtllibs:
+        p = rel if os.path.isabs(rel) else os.path.join(parent, rel)
+        try:
+            with open(p, "r", errors="replace") as f:
+                mats = parse_mtl(f.read())
+        except OSError:
+            continue            # obj_parser.rs:163: a missing MTL is skipped silently
+        for m in mats:
+            if m.map_kd:
+                m.map_kd = m.map_kd if os.path.isabs(m.map_kd) else os.path.normpath(os.path.join(os.path.dirname(p), m.map_kd))
+                if texture_paths is not None and os.path.isfile(m.map_kd):
+                    texture_paths.add(m.map_kd)
+        materials += mats
+    return obj_to_mesh(obj, materials)
+
+
+_VEC3 = ("x", "y", "z")
+
+
+def _vec3(d, what):
+    if not isinstance(d, dict) or any(k not in d or isinstance(d[k], bool) or not isinstance(d[k], (int, float)) for k in _VEC3):
+        raise SceneFileError(f"{what}: expected {{x, y, z}} numbers")
+    return [float(d["x"]), float(d["y"]), float(d["z"])]
+
+
+def _color(d, what):
+    if not isinstance(d, dict) or any(k not in d or not isinstance(d[k], (int, float)) for k in ("r", "g", "b")):
+        raise SceneFileError(f"{what}: expected {{r, g, b}} numbers")
+    return [float(d["r"]), float(d["g"]), float(d["b"])]
+
+
+def parse_scene_file(text: str) -> dict:
+    """SceneFile (scene_io_objects.rs:6-120) from JSON text; the required members are the ones
+    serde needs (scene_name, objects, lights, camera, background_color; misc optional)."""
+    try:
+        j = json.loads(text)
+    except json.JSONDecodeError as e:
+        raise SceneFileError(f"not JSON: {e}") from None
+    if not isinstance(j, dict):
+        raise SceneFileError("JSON does not comply with Schema")
+    for k in ("scene_name", "objects", "lights", "camera", "background_color"):
+        if k not in j:
+            raise SceneFileError(f"JSON does not comply with Schema: missing {k}")
+    cam = j["camera"]
+    for k in ("position", "look_at", "up", "pane_distance", "pane_width", "resolution"):
+        if k not in cam:
+            raise SceneFileError(f"JSON does not comply with Schema: camera.{k}")
+    out = {
+        "scene_name": str(j["scene_name"]),
+        "background_color": _color(j["background_color"], "background_color"),
+        "camera": {
+            "position": _vec3(cam["position"], "camera.position"), "look_at": _vec3(cam["look_at"], "camera.look_at"),
+            "pane_distance": float(cam["pane_distance"]), "pane_width": float(cam["pane_width"]),
+            "resolution": (int(cam["resolution"]["x"]), int(cam["resolution"]["y"])),
+        },
+        "objects": [], "lights": [], "spheres": [], "ray_samples": None, "hash_color": None,
+    }
+    for i, o in enumerate(j["objects"]):
+        for k in ("name", "path", "scale", "translation", "rotation"):
+            if k not in o:
+                raise SceneFileError(f"JSON does not comply with Schema: objects[{i}].{k}")
+        out["objects"].append({"name": o["name"], "path": o["path"], "scale": _vec3(o["scale"], "scale"),
+                               "translation": _vec3(o["translation"], "translation"), "rotation": _vec3(o["rotation"], "rotation")})
+    for i, l in enumerate(j["lights"]):
+        for k in ("name", "type", "position", "luminosity", "color"):
+            if k not in l:
+                raise SceneFileError(f"JSON does not comply with Schema: lights[{i}].{k}")
+        out["lights"].append({"name": l["name"], "position": _vec3(l["position"], "position"),
+                              "luminosity": float(l["luminosity"]), "color": _color(l["color"], "color")})
+    misc = j.get("misc") or {}
+    for i, s in enumerate(misc.get("spheres") or []):
+        for k in ("center", "radius", "color"):
+            if k not in s:
+                raise SceneFileError(f"JSON does not comply with Schema: misc.spheres[{i}].{k}")
+        out["spheres"].append({"center": _vec3(s["center"], "center"), "radius": float(s["radius"]),
+                               "color": _color(s["color"], "color"), "material": s.get("material")})
+    if misc.get("ray_samples") is not None:
+        out["ray_samples"] = int(misc["ray_samples"])
+    if misc.get("hash_color") is not None:
+        out["hash_color"] = bool(misc["hash_color"])
+    return out
+
+
+def _find_scene_json(root: str) -> str:
+    """FileManager::find_scene_json (file_manager.rs:68-110): the first scene.json, else the first .json."""
+    fallback = None
+    for d, _, files in sorted(os.walk(root)):
+        for f in sorted(files):
+            if f == "scene.json":
+                return os.path.join(d, f)
+            if f.endswith(".json") and fallback is None:
+                fallback = os.path.join(d, f)
+    if fallback is None:
+        raise SceneFileError("no scene.json in the archive")
+    return fallback
+
+
+def _resolve(p: str, base: str, included_root: Optional[str]) -> str:
+    """AutoPath::get_absolute_or_join (included_files.rs): ``$INCLUDED/...`` names a file shipped
+    with the application, anything relative is joined to the scene file's directory."""
+    if p.startswith("$INCLUDED"):
+        root = included_root or os.environ.get("RENDERBABY_INCLUDED")
+        if not root:
+            raise FileNotFoundError(f"{p}: no included_root given for $INCLUDED paths")
+        return os.path.join(root, p[len("$INCLUDED"):].lstrip("/\\"))
+    return p if os.path.isabs(p) else os.path.join(base, p)
+
+
+def load_scene(path: str, json_string: Optional[str] = None, extract_dir: Optional[str] = None, max_depth=5,
+               ground_enabled=1, ground_height=-1.0, checkerboard_enabled=1, total_samples=None, bvh_builder=None,
+               included_root: Optional[str] = None):
+    """Scene::load_scene_from_path (render_scene.rs:47-77,186-210) + parse_scene
+    (scene_importer.rs:140-229) + generate_full_render_command_builder: a ``.json`` scene file or a
+    ``.rscn`` archive (zip with a scene.json and its assets) -> flat ``scenes.Scene`` ready for
+    ``RenderConfig.from_scene``.  Render parameters that are not part of the file (ground,
+    checkerboard, max depth) default to ``RenderParameter::default()`` (render_parameter.rs:17-33)."""
+    is_rscn = path.lower().endswith(".rscn")
+    if is_rscn:
+        import tempfile
+        extract_dir = extract_dir or tempfile.mkdtemp(prefix="renderbaby_import_")
+        try:
+            with zipfile.ZipFile(path) as z:
+                for info in z.infolist():
+                    target = os.path.normpath(os.path.join(extract_dir, info.filename))
+                    if not target.startswith(os.path.abspath(extract_dir)):   # enclosed_name(): no escapes
+                        continue
+                    z.extract(info, extract_dir)
+        except zipfile.BadZipFile as e:
+            raise SceneFileError(f"not a scene archive: {e}") from None
+        json_path = _find_scene_json(extract_dir)
+        with open(json_path, "r") as f:
+            text = f.read()
+        base = os.path.dirname(json_path)
+    elif json_string is not None:
+        text, base = json_string, os.path.dirname(os.path.abspath(path)) if path else os.getcwd()
+    else:
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"File {path} does not exist!")
+        with open(path, "r") as f:
+            text = f.read()
+        base = os.path.dirname(os.path.abspath(path))
+    sf = parse_scene_file(text)
+
+    tex_paths: set = set()
+    meshes = []
+    for o in sf["objects"]:
+        m = load_obj_file(_resolve(o["path"], base, included_root), tex_paths)
+        meshes.append(transform_mesh(m, o["scale"][0], o["rotation"], o["translation"]))
+    # texture indices follow the sorted paths (texture_loader.rs:44-49)
+    tex_order = sorted(tex_paths)
+    textures = [load_texture(p) for p in tex_order]
+    tex_map = {p: i for i, p in enumerate(tex_order)}
+
+    spheres = np.zeros(len(sf["spheres"]), abi.SPHERE)
+    for i, s in enumerate(sf["spheres"]):
+        ref = s["material"]
+        if isinstance(ref, dict) and "preset" in ref:
+            om = preset_material(str(ref["preset"]))
+        elif isinstance(ref, dict) and "path" in ref and "name" in ref:
+            p = _resolve(ref["path"], base, included_root)
+            with open(p, "r", errors="replace") as f:
+                found = [m for m in parse_mtl(f.read()) if m.name == ref["name"]]
+            if not found:
+                raise SceneFileError(f"Material with name {ref['name']} not found in file {p}")
+            om = found[0]
+        else:
+            om = PRESETS[DEFAULT_PRESET]
+        spheres[i]["center"], spheres[i]["radius"] = s["center"], s["radius"]
+        spheres[i]["material"] = material_to_render_material(om, s["color"])
+    lights = np.zeros(len(sf["lights"]), abi.POINT_LIGHT)
+    for i, l in enumerate(sf["lights"]):
+        lights[i] = point_light(l["position"], l["luminosity"], l["color"])
+
+    cam = sf["camera"]
+    pos, look = _f32(cam["position"]), _f32(cam["look_at"])
+    color_hash = 0 if is_rscn else (1 if sf["hash_color"] is None else int(sf["hash_color"]))   # render_scene.rs:201-204
+    spp = total_samples if total_samples is not None else (sf["ray_samples"] if sf["ray_samples"] is not None else 1)
+    u = scenes.make_uniforms(cam["resolution"][0], cam["resolution"][1], spp, max_depth, cam_pos=pos,
+                             cam_dir=(look - pos).astype(np.float32), pane_distance=cam["pane_distance"],
+                             pane_width=cam["pane_width"], ground_enabled=ground_enabled, ground_height=ground_height,
+                             checkerboard_enabled=checkerboard_enabled, sky=sf["background_color"], color_hash=color_hash)
+    groups, uv_groups = [], []
+    for m in meshes:
+        g, uvg = mesh_to_render_groups(m, tex_map)
+        groups += g
+        uv_groups += uvg
+    return scenes._finish(sf["scene_name"], u, spheres, lights, groups, uv_groups, textures, bvh_builder=bvh_builder)
+
+
+def export_png(path: str, frame) -> None:
+    """export_img_png (img_export.rs:5-18): the Frame's RGBA8 pixels, row-major, as a PNG."""
+    from PIL import Image
+    px = np.asarray(frame.pixels, dtype=np.uint8).reshape(frame.height, frame.width, 4)
+    if px.size != frame.width * frame.height * 4:
+        raise ValueError("DimensionMismatch")
+    Image.fromarray(px, "RGBA").save(path, format="PNG")

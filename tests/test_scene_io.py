@@ -104,3 +104,233 @@ def test_reference_cornell_fixture_bit_exact_on_gpu(kernel):
     e.close()
     assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)
     assert {k: st[k] for k in _oracle.STAT_KEYS} == o_st
+
+
+# ------------------------------------------------------------------ scene files (.json / .rscn)
+import json
+import os
+import zipfile
+
+CUBE_OBJ = """mtllib cube.mtl
+v -1 -1 -1
+v 1 -1 -1
+v 1 1 -1
+v -1 1 -1
+v -1 -1 1
+v 1 -1 1
+v 1 1 1
+v -1 1 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+usemtl skin
+f 1/1 2/2 3/3 4/4
+f 5/1 8/4 7/3 6/2
+usemtl lamp
+f 1 5 6 2
+f 2 6 7 3
+f 3 7 8 4
+f 5 1 4 8
+"""
+CUBE_MTL = """newmtl skin
+Kd 1 1 1
+map_Kd skin.png
+newmtl lamp
+Kd 0 0 0
+Ke 4 4 4
+"""
+
+
+def _scene_json(objects=True, misc=True):
+    j = {
+        "scene_name": "loader-test",
+        "objects": [{"name": "cube", "path": "obj/cube.obj", "scale": {"x": 0.5, "y": 0.5, "z": 0.5},
+                     "translation": {"x": 0.0, "y": 1.0, "z": -4.0}, "rotation": {"x": 0.0, "y": 30.0, "z": 0.0}}] if objects else [],
+        "lights": [{"name": "L", "type": "point", "position": {"x": 2.0, "y": 4.0, "z": 1.0}, "luminosity": 20.0,
+                    "color": {"r": 1.0, "g": 0.9, "b": 0.8}}],
+        "camera": {"position": {"x": 0.0, "y": 1.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 1.0, "z": -4.0},
+                   "up": {"x": 0.0, "y": 1.0, "z": 0.0}, "pane_distance": 35.0, "pane_width": 36.0,
+                   "resolution": {"x": 40, "y": 30}},
+        "background_color": {"r": 0.2, "g": 0.3, "b": 0.4},
+    }
+    if misc:
+        j["misc"] = {"spheres": [{"center": {"x": 1.5, "y": 0.5, "z": -3.0}, "radius": 0.5, "material": {"preset": "plastic"},
+                                  "color": {"r": 1.0, "g": 0.0, "b": 0.0}, "name": "s", "scale": {"x": 1, "y": 1, "z": 1},
+                                  "translation": {"x": 0, "y": 0, "z": 0}, "rotation": {"x": 0, "y": 0, "z": 0}},
+                                 {"center": {"x": -1.5, "y": 0.5, "z": -3.0}, "radius": 0.5, "material": {"preset": "nosuch"},
+                                  "color": {"r": 1.0, "g": 1.0, "b": 1.0}, "name": "m", "scale": {"x": 1, "y": 1, "z": 1},
+                                  "translation": {"x": 0, "y": 0, "z": 0}, "rotation": {"x": 0, "y": 0, "z": 0}}],
+                     "ray_samples": 3, "hash_color": False}
+    return j
+
+
+def _write_scene_dir(root, **kw):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "obj"), exist_ok=True)
+    with open(os.path.join(root, "obj", "cube.obj"), "w") as f:
+        f.write(CUBE_OBJ)
+    with open(os.path.join(root, "obj", "cube.mtl"), "w") as f:
+        f.write(CUBE_MTL)
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[0, 0], tex[0, 1], tex[1, 0], tex[1, 1] = (255, 0, 0, 255), (0, 255, 0, 255), (0, 0, 255, 255), (255, 255, 255, 255)
+    Image.fromarray(tex, "RGBA").save(os.path.join(root, "obj", "skin.png"))
+    p = os.path.join(root, "scene.json")
+    with open(p, "w") as f:
+        json.dump(_scene_json(**kw), f)
+    return p
+
+
+def test_euler_and_mesh_transform_known_answers():
+    # yaw 90 deg about z takes +x to +y; pitch 90 about y takes +x to -z; roll 90 about x takes +y to +z
+    np.testing.assert_allclose(scene_io.euler_zyx((0, 0, 90)) @ [1, 0, 0], [0, 1, 0], atol=1e-6)
+    np.testing.assert_allclose(scene_io.euler_zyx((0, 90, 0)) @ [1, 0, 0], [0, 0, -1], atol=1e-6)
+    np.testing.assert_allclose(scene_io.euler_zyx((90, 0, 0)) @ [0, 1, 0], [0, 0, 1], atol=1e-6)
+    # Rz * Ry * Rx order: x-roll is applied first
+    np.testing.assert_allclose(scene_io.euler_zyx((90, 0, 90)) @ [0, 1, 0], [0, 0, 1], atol=1e-6)
+    # scale and rotation are about the centroid, translation afterwards (mesh.rs:104-123,200-225)
+    v = np.array([[0, 0, 0], [2, 0, 0], [1, 3, 0]], np.float32)   # centroid (1, 1, 0)
+    m = scene_io.SceneMesh(v, np.zeros((3, 2), np.float32), np.zeros(1, np.int64), [])
+    t = scene_io.transform_mesh(m, 2.0, (0, 0, 90), (10, 0, 0))
+    np.testing.assert_allclose(t.vertices, [[13, -1, 0], [13, 3, 0], [7, 1, 0]], atol=1e-5)
+    np.testing.assert_allclose(t.vertices.mean(0), [11, 1, 0], atol=1e-5)
+
+
+def test_scene_json_is_loaded_with_the_references_conventions(tmp_path):
+    s = scene_io.load_scene(_write_scene_dir(str(tmp_path)))
+    u = s.uniforms[0]
+    assert (u["width"], u["height"], u["total_samples"], u["color_hash_enabled"]) == (40, 30, 3, 0)
+    np.testing.assert_array_equal(u["camera"]["pos"], [0, 1, 3])
+    np.testing.assert_array_equal(u["camera"]["dir"], [0, 0, -7])          # look_at - position, not normalised
+    np.testing.assert_allclose(u["sky_color"], [0.2, 0.3, 0.4])
+    assert (u["ground_enabled"], u["checkerboard_enabled"], u["max_depth"]) == (1, 1, 5)   # RenderParameter::default
+    assert u["ground_height"] == -1.0
+    # 6 quads -> 12 un-indexed triangles in two sub-meshes (skin: 4, lamp: 8)
+    assert len(s.bvh_triangles) == 12 and len(s.meshes) == 2 and u["bvh_triangle_count"] == 12
+    assert s.meshes[0]["material"]["texture_index"] == 0 and s.meshes[1]["material"]["texture_index"] == -1
+    np.testing.assert_array_equal(s.meshes[1]["material"]["emissive"], [4, 4, 4])
+    # the cube: half size 0.5 after scale, centred at (0, 1, -4), rotated 30 deg about y
+    v = np.concatenate([s.bvh_triangles["v0"], s.bvh_triangles["v1"], s.bvh_triangles["v2"]])
+    np.testing.assert_allclose(v.mean(0), [0, 1, -4], atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(v - [0, 1, -4], axis=1), np.sqrt(0.75), atol=1e-5)
+    np.testing.assert_allclose(np.unique(np.round(v[:, 1], 5)), [0.5, 1.5])
+    c30, s30 = np.cos(np.pi / 6), np.sin(np.pi / 6)
+    corner = np.array([0.5 * c30 + 0.5 * s30, 0.5, -4 - 0.5 * s30 + 0.5 * c30])   # Ry(30) * (0.5, -0.5, 0.5) + centre
+    assert np.min(np.linalg.norm(v - corner, axis=1)) < 1e-5
+    # texture: RGBA8, R in the low byte; uvs carried per un-indexed vertex
+    assert len(s.textures) == 1 and s.textures[0][:2] == (2, 2)
+    assert list(s.textures[0][2]) == [0xFF0000FF, 0xFF00FF00, 0xFFFF0000, 0xFFFFFFFF]
+    assert len(s.uvs) == 12 * 3 * 2
+    # spheres: plastic x red; unknown preset -> Material::default() = mirror; emissive x 500 only where Ke > 0
+    assert len(s.spheres) == 2
+    np.testing.assert_array_equal(s.spheres[0]["material"]["diffuse"], [1, 0, 0])
+    np.testing.assert_array_equal(s.spheres[1]["material"]["specular"], [1, 1, 1])
+    assert s.spheres[1]["material"]["shininess"] == 1000.0
+    # light: a renderable emissive sphere of radius 0.5
+    assert len(s.lights) == 1 and s.lights[0]["radius"] == 0.5
+    np.testing.assert_allclose(s.lights[0]["material"]["emissive"], [20, 18, 16])
+    # and the flat scene renders through the oracle
+    acc, _, rgba, st = _oracle.render(s)
+    assert rgba.shape == (30, 40, 4) and st["mesh_hits"] > 0 and st["spheres_tested"] > 0
+
+
+def test_scene_without_misc_uses_defaults(tmp_path):
+    s = scene_io.load_scene(_write_scene_dir(str(tmp_path), misc=False))
+    u = s.uniforms[0]
+    assert len(s.spheres) == 0 and u["total_samples"] == 1 and u["color_hash_enabled"] == 1   # tests.rs:352-381
+
+
+def test_rscn_archive_round_trip_and_color_hash_off(tmp_path):
+    src = tmp_path / "src"
+    _write_scene_dir(str(src), misc=False)
+    rscn = str(tmp_path / "bundle.rscn")
+    with zipfile.ZipFile(rscn, "w") as z:
+        for d, _, files in os.walk(src):
+            for f in files:
+                full = os.path.join(d, f)
+                z.write(full, os.path.join("scene", os.path.relpath(full, src)))
+    a = scene_io.load_scene(rscn, extract_dir=str(tmp_path / "x1"))
+    b = scene_io.load_scene(rscn, extract_dir=str(tmp_path / "x2"))          # tests.rs:181-212 idempotency
+    assert a.uniforms[0]["color_hash_enabled"] == 0                          # tests.rs:243-263
+    assert len(a.bvh_triangles) == 12 and a.name == "loader-test"
+    assert np.array_equal(a.bvh_triangles, b.bvh_triangles) and np.array_equal(a.uniforms, b.uniforms)
+
+
+def test_scene_file_errors(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        scene_io.load_scene(str(tmp_path / "fake.json"))                     # tests.rs:152-158
+    bad = str(tmp_path / "bad.rscn")
+    with zipfile.ZipFile(bad, "w") as z:
+        z.writestr("dummy.txt", "hello")
+    with pytest.raises(scene_io.SceneFileError):
+        scene_io.load_scene(bad, extract_dir=str(tmp_path / "x"))            # tests.rs:160-179
+    j = _scene_json(objects=False)
+    del j["camera"]["pane_width"]
+    with pytest.raises(scene_io.SceneFileError):
+        scene_io.load_scene("", json_string=json.dumps(j))
+    with pytest.raises(scene_io.SceneFileError):
+        scene_io.load_scene("", json_string="{not json")
+    ok = scene_io.load_scene("", json_string=json.dumps(_scene_json(objects=False)))
+    assert len(ok.bvh_triangles) == 0 and len(ok.spheres) == 2
+
+
+def test_png_export_round_trip(tmp_path):
+    from PIL import Image
+    from renderbaby_amd.engine import Frame
+    px = (np.arange(5 * 3 * 4) % 256).astype(np.uint8)
+    p = str(tmp_path / "out.png")
+    scene_io.export_png(p, Frame(5, 3, px))
+    back = np.asarray(Image.open(p))
+    assert back.shape == (3, 5, 4) and np.array_equal(back.reshape(-1), px)
+
+
+@pytest.mark.gpu
+def test_loaded_scene_file_renders_bit_exact_on_gpu(tmp_path):
+    # file -> loader -> adapter -> C ABI -> kernels, against the oracle on the same flat scene:
+    # textured cube (sRGB table), emissive faces, preset spheres, point light, checkerboard ground
+    from renderbaby_amd import Engine, RenderConfig
+    s = scene_io.load_scene(_write_scene_dir(str(tmp_path)), total_samples=6)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, stats=True)
+    f = e.render(rc)
+    acc, st = e.read_accumulation(), e.stats()
+    e.close()
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)
+    assert {k: st[k] for k in _oracle.STAT_KEYS} == o_st
+    p = str(tmp_path / "frame.png")
+    scene_io.export_png(p, f)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p)).reshape(-1), np.asarray(f.pixels).reshape(-1))
+
+
+def test_reference_lamp_scene_fixture_matches_the_rscn_file():
+    # the committed DATA fixture is what the loader makes of the reference's .rscn (dev container only)
+    src = "/root/reference/included/fixtures/scenes/final_cornell_with_lamp_and_spheres.rscn"
+    a = _refscenes.ref_lamp()
+    u = a.uniforms[0]
+    assert (len(a.bvh_triangles), len(a.spheres), u["width"], u["height"], u["total_samples"]) == (68768, 4, 2056, 2056, 512)
+    assert u["color_hash_enabled"] == 0 and len(a.bvh_nodes) == 2047
+    if not os.path.isfile(src):
+        pytest.skip("reference checkout not present")
+    b = scene_io.load_scene(src)
+    for k in ("uniforms", "spheres", "lights", "meshes", "bvh_triangles", "bvh_nodes", "bvh_indices", "uvs"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exact", "host-sah", "device-lbvh"])
+def test_reference_lamp_scene_bit_exact_on_gpu(mode):
+    from renderbaby_amd import Engine, RenderConfig
+    s = _refscenes.ref_lamp(width=96, height=96, spp=2)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, stats=True, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-lbvh"))
+    f = e.render(rc)
+    acc, st = e.read_accumulation(), e.stats()
+    assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
+    e.close()
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)
+    assert st["segments"] == o_st["segments"]
+    if mode == "exact":
+        assert {k: st[k] for k in _oracle.STAT_KEYS} == o_st

@@ -12,6 +12,9 @@ elif w == "c3": s = scenes.mesh_scene(112, 112, 1920, 1080, spp, 5)
 elif w == "c4": s = scenes.spheres_scene(1_000_000, 4096, 4096, spp, 5)
 elif w == "c4s": s = scenes.spheres_scene(1_000_000, 1024, 1024, spp, 5)
 elif w.startswith("mesh:"): s = scenes.mesh_scene(int(w[5:]), int(w[5:]), 1920, 1080, spp, 5)
+elif w == "lamp":
+    from tests import _refscenes
+    s = _refscenes.ref_lamp(spp=spp)
 elif w == "c5s": s = scenes.mesh_scene(1024, 512, 1920, 1080, spp, 16, seed=11, with_blob=False)
 rc = RenderConfig.from_scene(s)
 eng = Engine.new(rc, kernel=kern, fast_bvh=bool(int(os.environ.get('RB_FAST', '0'))), device_bvh=bool(int(os.environ.get('RB_DEVICE_BVH', '0'))), stats=bool(int(os.environ.get('RB_STATS', '0'))), lds_mode=int(os.environ.get('RB_LDS_MODE', '0'))); eng.update(rc)

@@ -228,12 +228,37 @@ def _f32(x):
     return np.asarray(x, dtype=np.float32)
 
 
-def _centroid(v: np.ndarray) -> np.ndarray:
-    # Mesh::calculate_centroid (mesh.rs:146-166): sequential f32 sums, then / n
+def calculate_centroid(v: np.ndarray) -> np.ndarray:
+    """Mesh::calculate_centroid (mesh.rs:146-166): sequential f32 sums over the vertices, then / n."""
+    v = np.asarray(v, np.float32).reshape(-1, 3)
+    if len(v) == 0:
+        raise ValueError("Cannot calculate centroid of 0 points")
     s = np.zeros(3, np.float32)
     for p in v:
         s = (s + p).astype(np.float32)
     return (s / np.float32(len(v))).astype(np.float32)
+
+
+_centroid = calculate_centroid
+
+
+def mesh_translate(v: np.ndarray, vec) -> np.ndarray:
+    """Mesh::translate (mesh.rs:217-225)."""
+    return (np.asarray(v, np.float32).reshape(-1, 3) + _f32(vec)).astype(np.float32)
+
+
+def mesh_scale(v: np.ndarray, factor: float) -> np.ndarray:
+    """Mesh::scale (mesh.rs:200-213): centroid + (v - centroid) * factor."""
+    v = np.asarray(v, np.float32).reshape(-1, 3)
+    c = calculate_centroid(v)
+    return (c + (v - c) * np.float32(factor)).astype(np.float32)
+
+
+def mesh_rotate(v: np.ndarray, rotation_deg) -> np.ndarray:
+    """Mesh::rotate (mesh.rs:104-123,229-248): ZYX Euler matrix applied about the centroid."""
+    v = np.asarray(v, np.float32).reshape(-1, 3)
+    c = calculate_centroid(v)
+    return ((v - c) @ euler_zyx(rotation_deg).T + c).astype(np.float32)
 
 
 def euler_zyx(rotation_deg) -> np.ndarray:
@@ -251,15 +276,9 @@ def transform_mesh(mesh: SceneMesh, scale=1.0, rotation=(0.0, 0.0, 0.0), transla
     """load_object_from_file_relative (render_scene.rs:146-160): uniform scale about the centroid by
     scale.x (mesh.rs:200-213), ZYX Euler rotation about the centroid (mesh.rs:104-123,229-248), then
     translation (mesh.rs:217-225).  f32 throughout."""
-    v = mesh.vertices.astype(np.float32).copy()
-    if len(v) == 0:
+    if len(mesh.vertices) == 0:
         return mesh
-    c = _centroid(v)
-    v = (c + (v - c) * np.float32(scale)).astype(np.float32)
-    c = _centroid(v)
-    R = euler_zyx(rotation)
-    v = ((v - c) @ R.T + c).astype(np.float32)
-    v = (v + _f32(translation)).astype(np.float32)
+    v = mesh_translate(mesh_rotate(mesh_scale(mesh.vertices, scale), rotation), translation)
     return SceneMesh(v, mesh.uvs, mesh.material_index, mesh.materials)
 
 

@@ -181,6 +181,20 @@ def _write_scene_dir(root, **kw):
     return p
 
 
+def test_reference_mesh_test_known_answers():
+    # crates/scene-objects/src/lib.rs:38-81 (mesh_test): the reference's own known answers for
+    # calculate_centroid / translate / scale on the unit cube at (1..2)^3 -- exact equality there too
+    v = np.array([1, 1, 1, 2, 1, 1, 2, 2, 1, 1, 2, 1, 1, 1, 2, 2, 1, 2, 2, 2, 2, 1, 2, 2], np.float32).reshape(-1, 3)
+    assert np.array_equal(scene_io.calculate_centroid(v), [1.5, 1.5, 1.5])
+    moved = scene_io.mesh_translate(v, (-1.5, -1.5, -1.5))
+    assert np.array_equal(scene_io.calculate_centroid(moved), [0, 0, 0])
+    assert np.array_equal(moved, v - np.float32(1.5))
+    scaled = scene_io.mesh_scale(moved, 2.0)
+    assert np.array_equal(scaled, (v - np.float32(1.5)) * np.float32(2.0))
+    with pytest.raises(ValueError):
+        scene_io.calculate_centroid(np.zeros((0, 3), np.float32))     # mesh.rs:147-149
+
+
 def test_euler_and_mesh_transform_known_answers():
     # yaw 90 deg about z takes +x to +y; pitch 90 about y takes +x to -z; roll 90 about x takes +y to +z
     np.testing.assert_allclose(scene_io.euler_zyx((0, 0, 90)) @ [1, 0, 0], [0, 1, 0], atol=1e-6)

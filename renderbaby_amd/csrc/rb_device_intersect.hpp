@@ -236,40 +236,105 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 //  * boxes are inflated by a margin so rounding cannot cull a triangle the reference would hit.
 // Not a proof (an ill-conditioned Moller-Trumbore hit far outside its triangle could be missed),
 // which is why it is opt-in; the tests compare it bit for bit with the reference walk.
+// The walk is written as a resumable object so that the same steps serve the per-segment kernels
+// (intersect_bvh_fast below: run to completion) and the stepped kernel (k_trace_fast: lanes that
+// finish are shaded and refilled while the others keep walking).
 template <bool STATS>
-DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+struct FastWalk {
+    f3 o, d, inv;
+    float S;            // 0.01 * farthest the ray origin can be from any point of the mesh
     TriHit h;
-    h.hit = false;
-    h.t = 1e20f;
-    h.u = 0.0f;
-    h.v = 0.0f;
-    h.slot = 0u;
-    uint32_t best_rank = 0xFFFFFFFFu;
-    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
-    const cf4p nodes = (cf4p)p.fast_nodes;
-    const cf4p ftris = (cf4p)p.fast_tris;
-    const cf4p rnodes = (cf4p)p.nodes;
-    const RB_CONST uint32_t* fslots = cptr(p.fast_slots);
-    const RB_CONST uint32_t* meta = cptr(p.slot_meta);
-    const RB_CONST uint32_t* parent = cptr(p.ref_parent);
-    const float m = p.fast_margin;
-    // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
-    // triangle).  A child's box is inflated by m + 0.01 * S * (largest |e1||e2| below it): how far
-    // from its triangle a Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
-    const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
-    const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
-                sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
-    const float S = 0.01f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
+    uint32_t best_rank;
+    uint32_t cur;       // current child reference (leaf: bit 31)
+    int sp;
 
-    auto entry = [&](v4f lo, v4f hi, float amax, float& tn) -> bool {
-        const float mm = m + S * amax;
+    DEV void begin(const KParams& p, f3 o_, f3 d_) {
+        o = o_;
+        d = d_;
+        h.hit = false;
+        h.t = 1e20f;
+        h.u = 0.0f;
+        h.v = 0.0f;
+        h.slot = 0u;
+        best_rank = 0xFFFFFFFFu;
+        inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
+        // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
+        // triangle).  A child's box is inflated by m + 0.01 * S * (largest |e1||e2| below it): how far
+        // from its triangle a Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
+        const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
+        const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
+                    sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
+        S = 0.01f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
+        cur = p.fast_root;
+        sp = 0;
+    }
+    DEV bool at_leaf() const { return (cur & 0x80000000u) != 0u; }
+
+    // Entries beyond the LDS stack (trees deeper than kStackDepth: only device-built ones, the host
+    // builder limits its depth) spill to this lane's column of a global scratch array.
+    // (volatile on the spill side keeps the compiler from merging the two accesses into one through a
+    // generic pointer, which would turn every LDS stack access into a flat_load / flat_store)
+    DEV static volatile uint32_t* spill(const KParams& p, int at) {
+        return p.stack_overflow + ((size_t)(uint32_t)(at - (int)kStackDepth) * (gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x);
+    }
+    DEV static void push(const KParams& p, uint32_t* stack, uint32_t stride, int at, uint32_t v) {
+        if (__builtin_expect(at < (int)kStackDepth, 1)) stack[at * stride] = v;
+        else *spill(p, at) = v;
+    }
+    DEV static uint32_t peek(const KParams& p, const uint32_t* stack, uint32_t stride, int at) {
+        uint32_t v;
+        if (__builtin_expect(at < (int)kStackDepth, 1)) v = stack[at * stride];
+        else v = *spill(p, at);
+        return v;
+    }
+    // next pending subtree; false when the walk is complete
+    DEV bool pop(const KParams& p, const uint32_t* stack, uint32_t stride) {
+        if (sp == 0) return false;
+        sp--;
+        cur = peek(p, stack, stride, sp);
+        return true;
+    }
+
+    DEV bool entry(const KParams& p, v4f lo, v4f hi, float amax, float& tn) const {
+        const float mm = p.fast_margin + S * amax;
         const f3 t0 = (mk(lo.x - mm, lo.y - mm, lo.z - mm) - o) * inv;
         const f3 t1 = (mk(hi.x + mm, hi.y + mm, hi.z + mm) - o) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
-    };
-    auto reference_would_test = [&](uint32_t leaf_node) -> bool {
+    }
+
+    // cur is an internal node: descend into the nearer child that is hit, remember the other.
+    // Returns false when the walk is complete.
+    DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        const cf4p nodes = (cf4p)p.fast_nodes;
+        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        if constexpr (STATS) tl.nodes++;
+        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+        float tl_, tr_;
+        const bool hl = entry(p, l0, l1, r0.w, tl_), hr = entry(p, r0, r1, r1.w, tr_);
+        if (hl && hr) {
+            const bool left_first = !(tr_ < tl_);
+            push(p, stack, stride, sp, left_first ? rref : lref);
+            sp++;
+            cur = left_first ? lref : rref;
+            return true;
+        }
+        if (hl) {
+            cur = lref;
+            return true;
+        }
+        if (hr) {
+            cur = rref;
+            return true;
+        }
+        return pop(p, stack, stride);
+    }
+
+    DEV bool reference_would_test(const KParams& p, uint32_t leaf_node, Tally<STATS>& tl) const {
+        const cf4p rnodes = (cf4p)p.nodes;
+        const RB_CONST uint32_t* parent = cptr(p.ref_parent);
+        const float m = p.fast_margin;
         // Shortcut: if the ray passes through the reference LEAF's box shrunk by m on every side
         // (m is far above the rounding error of a slab test), it passes through the interior of
         // every ancestor's box, so each of the reference's slab tests succeeds; only a ray that
@@ -294,9 +359,15 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
             if (n == 0u) return true;
             n = parent[n];
         }
-    };
-    auto leaf = [&](uint32_t ref) {
-        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
+    }
+
+    // cur is a leaf (1 or 2 triangles): test them, then take the next pending subtree.
+    // Returns false when the walk is complete.
+    DEV bool leaf_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        const cf4p ftris = (cf4p)p.fast_tris;
+        const RB_CONST uint32_t* fslots = cptr(p.fast_slots);
+        const RB_CONST uint32_t* meta = cptr(p.slot_meta);
+        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 3u) + 1u;
         for (uint32_t j = first; j < first + count; j++) {
             const v4f a = ftris[j * 4u], b = ftris[j * 4u + 1u], c = ftris[j * 4u + 2u];
             if constexpr (STATS) tl.tris++;
@@ -305,7 +376,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
             if (t > 0.001f && !(t > h.t)) {
                 const uint32_t slot = fslots[j];
                 const uint32_t leaf_node = meta[slot * 2u], rank = meta[slot * 2u + 1u];
-                if ((t < h.t || rank < best_rank) && reference_would_test(leaf_node)) {
+                if ((t < h.t || rank < best_rank) && reference_would_test(p, leaf_node, tl)) {
                     h.hit = true;
                     h.t = t;
                     h.u = u;
@@ -316,50 +387,17 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
                 }
             }
         }
-    };
-
-    // Entries beyond the LDS stack (trees deeper than kStackDepth: only device-built ones, the host
-    // builder limits its depth) spill to this lane's column of a global scratch array.
-    uint32_t* const ovf = p.stack_overflow + (blockIdx.x * blockDim.x + threadIdx.x);
-    const uint32_t ovf_stride = gridDim.x * blockDim.x;
-    auto push = [&](int at, uint32_t v) {
-        if (at < (int)kStackDepth) stack[at * stride] = v;
-        else ovf[(uint32_t)(at - (int)kStackDepth) * ovf_stride] = v;
-    };
-    auto pop = [&](int at) -> uint32_t {
-        return (at < (int)kStackDepth) ? stack[at * stride] : ovf[(uint32_t)(at - (int)kStackDepth) * ovf_stride];
-    };
-    uint32_t cur = p.fast_root;
-    int sp = 0;
-    for (;;) {
-        if (cur & 0x80000000u) {
-            leaf(cur);
-            if (sp == 0) break;
-            sp--;
-            cur = pop(sp);
-            continue;
-        }
-        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
-        if constexpr (STATS) tl.nodes++;
-        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
-        float tl_, tr_;
-        const bool hl = entry(l0, l1, r0.w, tl_), hr = entry(r0, r1, r1.w, tr_);
-        if (hl && hr) {
-            const bool left_first = !(tr_ < tl_);
-            push(sp, left_first ? rref : lref);
-            sp++;
-            cur = left_first ? lref : rref;
-        } else if (hl) {
-            cur = lref;
-        } else if (hr) {
-            cur = rref;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            cur = pop(sp);
-        }
+        return pop(p, stack, stride);
     }
-    return h;
+};
+
+template <bool STATS>
+DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+    FastWalk<STATS> w;
+    w.begin(p, o, d);
+    bool more = true;
+    while (more) more = w.at_leaf() ? w.leaf_step(p, stack, stride, tl) : w.node_step(p, stack, stride, tl);
+    return w.h;
 }
 
 template <bool STATS>

@@ -169,7 +169,7 @@ class Engine:
     """``engine_pathtracer::Engine`` for the HIP backend."""
 
     def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
-                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False):
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False):
         self._lib = load()
         cfg, keep = rc.to_c()
         opt = abi.Options()
@@ -181,6 +181,7 @@ class Engine:
             | (abi.FLAG_FAST_BVH if (fast_bvh or device_bvh) else 0) | (abi.FLAG_DEVICE_BVH if device_bvh else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
+        opt._reserved[3] = 1 if no_leaf_stepping else 0   # ablation: per-segment traversal for multi-node trees
         opt._reserved[4] = int(lds_mode)   # LDS staging of small meshes: 0 = when it fits, 1 = never
         self._h = self._lib.rb_create_ex(C.byref(cfg), C.byref(opt))
         del keep

@@ -60,53 +60,47 @@ DEV bool near_zero(f3 v) {                                                // :46
 //    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 D^2) from its centre and the
 //    reported t can be early by about the same amount; D = the farthest the ray origin can be
 //    from any sphere.  m = 3e-3 * D (> 2 * sqrt(1e-6) * D) bounds both.
-DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx,
-                               uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
-    const cf4p nodes = (cf4p)p.sph_nodes;
-    const cf4p leafs = (cf4p)p.sph_leaf;
-    const RB_CONST uint32_t* ids = cptr(p.sph_id);
-    const f3 bmin = ld3(p.sph_bmin), bmax = ld3(p.sph_bmax);
-    const float dx = fmaxf(fabsf(o.x - bmin.x), fabsf(o.x - bmax.x));
-    const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
-    const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
-    const float m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
-    const f3 inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
-    float best = closest_t;
-    uint32_t best_id = 0xFFFFFFFFu;
+// Resumable (like FastWalk): the per-segment kernels run it to completion, k_trace_sph steps it.
+struct SphereWalk {
+    f3 o, d, inv;
+    float a, m, best;
+    uint32_t best_id, cur;
+    int sp;
 
+    DEV void begin(const KParams& p, f3 o_, f3 d_, float a_, float closest_t) {
+        o = o_;
+        d = d_;
+        a = a_;
+        const f3 bmin = ld3(p.sph_bmin), bmax = ld3(p.sph_bmax);
+        const float dx = fmaxf(fabsf(o.x - bmin.x), fabsf(o.x - bmax.x));
+        const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
+        const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
+        m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
+        inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
+        best = closest_t;
+        best_id = 0xFFFFFFFFu;
+        cur = p.sph_root;
+        sp = 0;
+    }
+    DEV bool at_leaf() const { return (cur & 0x80000000u) != 0u; }
+    DEV bool pop(const uint32_t* stack, uint32_t stride) {
+        if (sp == 0) return false;
+        sp--;
+        cur = stack[sp * stride];
+        return true;
+    }
     // slab test of a box inflated by m: visit unless missed or entered beyond `best`
     // (comparisons are written so that a NaN means "visit")
-    auto entry = [&](v4f lo, v4f hi, float& tn) -> bool {
+    DEV bool entry(v4f lo, v4f hi, float& tn) const {
         const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
         const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > best);
-    };
-    auto leaf = [&](uint32_t ref) {
-        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 3u) + 1u;
-        for (uint32_t j = first; j < first + count; j++) {
-            const v4f cr = leafs[j];
-            const uint32_t id = ids[j];
-            if (n_tested) (*n_tested)++;
-            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-            if (t > 0.001f && (t < best || (t == best && id < best_id))) {
-                best = t;
-                best_id = id;
-            }
-        }
-    };
-
-    uint32_t cur = p.sph_root;
-    int sp = 0;
-    for (;;) {
-        if (cur & 0x80000000u) {
-            leaf(cur);
-            if (sp == 0) break;
-            sp--;
-            cur = stack[sp * stride];
-            continue;
-        }
+    }
+    // false when the walk is complete
+    DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride) {
+        const cf4p nodes = (cf4p)p.sph_nodes;
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
@@ -117,20 +111,49 @@ DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& clo
             stack[sp * stride] = left_first ? rref : lref;
             sp++;
             cur = left_first ? lref : rref;
-        } else if (hl) {
+            return true;
+        }
+        if (hl) {
             cur = lref;
-        } else if (hr) {
+            return true;
+        }
+        if (hr) {
             cur = rref;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            cur = stack[sp * stride];
+            return true;
+        }
+        return pop(stack, stride);
+    }
+    DEV bool leaf_step(const KParams& p, uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
+        const cf4p leafs = (cf4p)p.sph_leaf;
+        const RB_CONST uint32_t* ids = cptr(p.sph_id);
+        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 3u) + 1u;
+        for (uint32_t j = first; j < first + count; j++) {
+            const v4f cr = leafs[j];
+            const uint32_t id = ids[j];
+            if (n_tested) (*n_tested)++;
+            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+            if (t > 0.001f && (t < best || (t == best && id < best_id))) {
+                best = t;
+                best_id = id;
+            }
+        }
+        return pop(stack, stride);
+    }
+    DEV void result(float& closest_t, uint32_t& sphere_idx) const {
+        if (best_id != 0xFFFFFFFFu) {
+            closest_t = best;
+            sphere_idx = best_id;
         }
     }
-    if (best_id != 0xFFFFFFFFu) {
-        closest_t = best;
-        sphere_idx = best_id;
-    }
+};
+
+DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx,
+                               uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
+    SphereWalk w;
+    w.begin(p, o, d, a, closest_t);
+    bool more = true;
+    while (more) more = w.at_leaf() ? w.leaf_step(p, stack, stride, n_tested) : w.node_step(p, stack, stride);
+    w.result(closest_t, sphere_idx);
 }
 
 // One iteration of the bounce loop, shader.wgsl:534-660.  Returns true when the
@@ -138,15 +161,23 @@ DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& clo
 // (ground, BVH, spheres, lights) and strict comparisons, so ties resolve the
 // same way; per-hit data that only the final winner needs (position, normal,
 // material, uv) is produced once, after the search.
+// segment_finish in three parts, so that the stepped sphere kernel (k_trace_sph) can run the sphere
+// walk between them one step at a time.
+struct SegState {
+    float closest_t;
+    uint32_t kind;
+    float uvx, uvy;   // closest_hit.uv / use_texture after the ground + BVH stage
+    bool use_tex, tri_won_a;
+};
+
+// Ground and the BVH winner, shader.wgsl:552-571
 template <bool STATS>
-DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
-                        Tally<STATS>& tl) {
+DEV SegState segment_pre(const KParams& p, const Path& pt, const TriHit th, Tally<STATS>& tl) {
     const f3 o = pt.o, d = pt.d;
     tl.segments++;
 
     float closest_t = 1e20f;
     uint32_t kind = K_NONE;
-    // state of closest_hit.uv / use_texture after the ground + BVH stage
     float uvx = 0.0f, uvy = 0.0f;
     bool use_tex = false;
 
@@ -170,14 +201,26 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
         kind = K_TRI;
     }
 
-    // Spheres :574-586 and point lights :590-601.  Two passes with the reference's arithmetic:
-    // pass 1 evaluates the discriminant of every sphere with wave-uniform scalar loads and
-    // records the candidates (disc >= 0) in a per-lane bit mask; pass 2 runs the sqrt/divide
-    // tail only for a lane's own candidates, in ascending index order, so the strict `<`
-    // keeps the same winner.  Most lanes have no candidate, so the expensive tail is issued
-    // once or twice per segment instead of once per sphere.
-    const float a = dot(d, d);
-    uint32_t sphere_idx = 0xFFFFFFFFu;
+    SegState st;
+    st.closest_t = closest_t;
+    st.kind = kind;
+    st.uvx = uvx;
+    st.uvy = uvy;
+    st.use_tex = use_tex;
+    st.tri_won_a = tri_won_a;
+    return st;
+}
+
+// Spheres :574-586 and point lights :590-601.  Two passes with the reference's arithmetic:
+// pass 1 evaluates the discriminant of every sphere with wave-uniform scalar loads and
+// records the candidates (disc >= 0) in a per-lane bit mask; pass 2 runs the sqrt/divide
+// tail only for a lane's own candidates, in ascending index order, so the strict `<`
+// keeps the same winner.  Most lanes have no candidate, so the expensive tail is issued
+// once or twice per segment instead of once per sphere.
+// Spheres, shader.wgsl:574-586 -- per-segment form (the sphere tree run to completion, or the scan)
+template <bool STATS>
+DEV void segment_spheres(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx, uint32_t* stack,
+                         uint32_t stride, Tally<STATS>& tl) {
     const uint32_t ns = p.u.spheres_count;
     const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
     if (p.sph_nodes != nullptr) {
@@ -209,6 +252,20 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
             }
         }
     }
+}
+
+// Point lights, sky, the winner's HitRecord, shading and scatter, shader.wgsl:590-660
+template <bool STATS>
+DEV bool segment_post(const KParams& p, Path& pt, const TriHit th, const SegState st, float closest_t, uint32_t sphere_idx,
+                      Tally<STATS>& tl) {
+    const f3 o = pt.o, d = pt.d;
+    const float a = dot(d, d);
+    uint32_t kind = st.kind;
+    float uvx = st.uvx, uvy = st.uvy;
+    bool use_tex = st.use_tex;
+    const bool tri_won_a = st.tri_won_a;
+    [[maybe_unused]] const uint32_t ns = p.u.spheres_count;
+    [[maybe_unused]] const cf4p sph4 = (cf4p)p.spheres;
     if (sphere_idx != 0xFFFFFFFFu) kind = K_SPHERE;
 
     uint32_t light_idx = 0xFFFFFFFFu;
@@ -371,6 +428,17 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
     pt.d = normalize(scattered);
     pt.depth++;
     return pt.depth < p.u.max_depth;
+}
+
+// One iteration of the bounce loop after the triangle traversal (`th`: its winner).
+template <bool STATS>
+DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
+                        Tally<STATS>& tl) {
+    const SegState st = segment_pre<STATS>(p, pt, th, tl);
+    float closest_t = st.closest_t;
+    uint32_t sphere_idx = 0xFFFFFFFFu;
+    segment_spheres<STATS>(p, pt.o, pt.d, dot(pt.d, pt.d), closest_t, sphere_idx, stack, stride, tl);
+    return segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
 }
 
 // One whole iteration of the bounce loop: traversal + everything else.

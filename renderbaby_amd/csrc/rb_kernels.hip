@@ -615,6 +615,142 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
     flush_tally<STATS>(tl, p.counters);
 }
 
+// The sphere tree (scenes with more than 64 spheres, BASELINE C4) stepped the same way: in the
+// per-segment form a wavefront walked it with 16 % of its lanes busy.  Used when there is no
+// multi-node triangle tree to walk as well.
+template <bool STATS>
+__global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const uint32_t total_items = tiles_x * tiles_y * S * 64u;
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    const Cam cam = make_cam(p);
+    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
+    uint32_t* const stack = &s_stack[tid];
+    Tally<STATS> tl;
+
+    enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
+    uint32_t state = IDLE;
+    bool exhausted = false;
+    uint32_t item = 0, loc_next = 0, loc_end = 0;
+    const uint32_t batch = p.queue_batch;
+    Path pt;
+    pt.depth = 0;
+    SphereWalk w;
+    w.begin(p, mk(0, 0, 0), mk(0, 0, 1), 1.0f, 1e20f);
+    TriHit th;
+    th.hit = false;
+    th.t = 1e20f;
+    th.u = th.v = 0.0f;
+    th.slot = 0u;
+    SegState st = segment_pre<STATS>(p, pt, th, tl);
+    tl.segments = 0;
+    unsigned long long* n_tested = nullptr;
+    if constexpr (STATS) n_tested = &tl.spheres;
+
+    for (;;) {
+        // ---- (1) hand items to idle lanes (same scheme as k_trace)
+        unsigned long long idle = __ballot(state == IDLE);
+        for (int round = 0; round < 2 && idle != 0ull; round++) {
+            if (loc_next == loc_end) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(p.queue, batch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= total_items) {
+                    exhausted = true;
+                    break;
+                }
+                loc_next = b;
+                loc_end = (total_items - b < batch) ? total_items : b + batch;
+            }
+            const uint32_t avail = loc_end - loc_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = (state == IDLE) && rank < avail;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t taken = n_idle < avail ? n_idle : avail;
+            if (take) {
+                const uint32_t it = loc_next + rank;
+                const uint32_t in = it & 63u, ts = it >> 6;
+                const uint32_t tile = ts / S, smp = ts - tile * S;
+                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
+                bool ok = (x < width) && (ly < p.local_rows);
+                uint32_t y = 0;
+                if (ok) {
+                    y = global_row(p, ly);
+                    ok = y < p.u.height;
+                }
+                if (ok) {
+                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                    item = it;
+                    if (p.u.max_depth > 0u) {
+                        state = BEGIN;
+                    } else {
+                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        tl.paths++;
+                    }
+                }
+            }
+            loc_next += taken;
+            idle = __ballot(state == IDLE);
+            if (taken == n_idle) break;
+        }
+        if (__ballot(state != IDLE) == 0ull) {
+            if (exhausted && loc_next == loc_end) break;
+            continue;
+        }
+
+        // ---- (2) start of a segment: the (at most single-node) triangle list, ground, then the
+        // sphere walk starts from what they left as the closest hit
+        if (state == BEGIN) {
+            th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, kTraceBlock, tl);
+            st = segment_pre<STATS>(p, pt, th, tl);
+            w.begin(p, pt.o, pt.d, dot(pt.d, pt.d), st.closest_t);
+            state = TRAV;
+        }
+
+        // ---- (3) walk.  Every pass is either a node step for all lanes at an inner node or a leaf
+        // step for all lanes at a leaf -- whichever has enough lanes to be worth issuing (a lane
+        // reaches a leaf only every ~6 nodes, so waiting for ALL lanes to reach one would leave the
+        // node loop 20 % occupied).  At least one pass per outer iteration, then on while enough lanes
+        // are still walking.
+        for (;;) {
+            const bool at_node = state == TRAV && !w.at_leaf();
+            const bool at_leaf = state == TRAV && w.at_leaf();
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+            if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
+                if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, n_tested)) state = FINISH;
+                if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
+            } else {
+                if (at_node && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
+            }
+            if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
+        }
+
+        // ---- (4) finished walks: lights, shading, next ray
+        if (state == FINISH) {
+            float closest_t = st.closest_t;
+            uint32_t sphere_idx = 0xFFFFFFFFu;
+            w.result(closest_t, sphere_idx);
+            const bool alive = segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
+            if (alive) {
+                state = BEGIN;
+            } else {
+                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                tl.paths++;
+                state = IDLE;
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
 // Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,
 // lane = pixel; each sample row is a contiguous 1 KiB read.
 __global__ void __launch_bounds__(256) k_accumulate(const KParams p) {
@@ -837,8 +973,9 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         const bool lds_big = stepped && p.lds_mode != 1u && lds * 4u + scene_lds <= 160u * 1024u;
         li.block = lds_big ? 1024u : kTraceBlock;
         const bool fast_stepped = p.fast_nodes != nullptr && p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
+        const bool sph_stepped_grid = !fast_stepped && !stepped && p.sph_nodes != nullptr && !p.no_leaf_stepping;
         // residency: k_trace 6 waves/SIMD, k_trace_fast 4 (registers)
-        li.grid = persistent_blocks(items, li.block, lds_big ? 1u : p.blocks_per_cu ? p.blocks_per_cu : fast_stepped ? 4u : 8u);
+        li.grid = persistent_blocks(items, li.block, lds_big ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (fast_stepped || sph_stepped_grid) ? 4u : 8u);
         if (li.grid == 0) return 0;
         // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64
         KParams q = p;
@@ -851,8 +988,14 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         q.queue_batch = (uint32_t)batch;
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
-        li.kernel_name = fast_stepped ? "k_trace_fast" : stepped ? (lds_big ? "k_trace_bvh_lds" : "k_trace_bvh") : "k_trace";
-        if (fast_stepped) {
+        const bool sph_stepped = !fast_stepped && !stepped && p.sph_nodes != nullptr && !p.no_leaf_stepping;
+        li.kernel_name = sph_stepped ? "k_trace_sph" : fast_stepped ? "k_trace_fast" : stepped ? (lds_big ? "k_trace_bvh_lds" : "k_trace_bvh") : "k_trace";
+        if (sph_stepped) {
+            if (stats)
+                hipLaunchKernelGGL(k_trace_sph<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
+            else
+                hipLaunchKernelGGL(k_trace_sph<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        } else if (fast_stepped) {
             if (stats)
                 hipLaunchKernelGGL(k_trace_fast<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
             else

@@ -166,6 +166,51 @@ def test_sharded_engines_reassemble_the_single_gpu_frame(kernel, world, stripe_r
     assert np.array_equal(frame, full)
 
 
+def _scene_for(which):
+    if which == "mesh":      # multi-node tree: k_trace_bvh / k_trace_bvh_lds / k_trace_fast
+        return scenes.mesh_scene(24, 24, 48, 36, 5, 5, seed=3)
+    return scenes.spheres_scene(n=3000, width=48, height=36, spp=5, max_depth=5, extent=12.0)   # k_trace_sph
+
+
+@pytest.mark.parametrize("which,kw,kernel_name", [
+    ("mesh", dict(), "k_trace_bvh_lds"), ("mesh", dict(lds_mode=1), "k_trace_bvh"),
+    ("mesh", dict(fast_bvh=True), "k_trace_fast"), ("mesh", dict(device_bvh=True), "k_trace_fast"),
+    ("spheres", dict(), "k_trace_sph"), ("spheres", dict(no_leaf_stepping=True), "k_trace")])
+def test_stepped_kernels_under_chunking_sharding_and_the_iterator(which, kw, kernel_name):
+    # the persistent, stepped kernels keep per-lane walk state across passes; cutting the work into
+    # launch chunks, row stripes or one-sample frames must not change a bit
+    import torch
+    from renderbaby_amd import dist as rdist
+    s = _scene_for(which)
+    rc = RenderConfig.from_scene(s)
+    o_acc, _, o_rgba, _ = _oracle.render(s)
+    eng = Engine.new(rc, **kw)
+    full = eng.render(rc)
+    assert eng.last_kernel_name() == kernel_name
+    assert np.array_equal(eng.read_accumulation().view(np.uint32), o_acc.view(np.uint32))
+    assert np.array_equal(full.pixels, o_rgba)
+    # progressive: frame k = running average of samples 0..k
+    it = eng.frame_iterator(RenderConfig.from_scene(s, create=False))
+    last = None
+    for k in range(s.total_samples):
+        last = it.next().pixels.copy()
+        if k == 1:
+            assert np.array_equal(last, _oracle.render(s, 0, 2)[2])
+    assert np.array_equal(last, o_rgba)
+    eng.close()
+    # launch chunking
+    eng = Engine.new(rc, passes_per_launch=2, **kw)
+    assert np.array_equal(eng.render(rc).pixels, o_rgba)
+    eng.close()
+    # row-stripe sharding
+    parts = []
+    for r in range(3):
+        e = Engine.new(rc, shard_rank=r, shard_count=3, stripe_rows=4, **kw)
+        parts.append(torch.from_numpy(e.render(rc).pixels.copy()))
+        e.close()
+    assert np.array_equal(rdist.assemble(parts, s.height, 4).numpy(), o_rgba)
+
+
 @pytest.mark.parametrize("n,extent,size", [(200, 6.0, 64), (10_000, 25.0, 192)])
 def test_sphere_bvh_matches_the_linear_scan(n, extent, size):
     # BASELINE C4 scaled down: the library's sphere acceleration structure must give

@@ -295,6 +295,12 @@ int rb_iter_has_next(rb_engine* e);
 int rb_iter_next(rb_engine* e, uint8_t* rgba_out);
 /* RaytracerFrameIterator::destroy -- lib.rs:231-233 */
 void rb_iter_destroy(rb_engine* e);
+/* Extension (per-N-pass delivery): every rb_iter_next advances `n` passes
+ * (the last one whatever is left) in one launch chunk and reads back once, so a frame is delivered
+ * every n samples instead of after each one -- the frames are the reference's frames n-1, 2n-1, ...
+ * and the last.  n = 0 or 1 is the reference's behaviour (the default; restored by rb_create only).
+ * Applies from the next rb_iter_next. */
+int rb_iter_set_passes_per_frame(rb_engine* e, uint32_t n);
 
 /* anyhow error text of the last failing call on `e` (or of rb_create when
  * e == NULL).  Valid until the next call on the same engine/thread. */

@@ -143,6 +143,10 @@ class Engine final : public Renderer {
         }
         void destroy() override { rb_iter_destroy(h_->e); }
     };
+    // extension: one frame per `n` samples instead of per sample (rb_iter_set_passes_per_frame)
+  public:
+    void set_passes_per_frame(uint32_t n) { check(h_->e, rb_iter_set_passes_per_frame(h_->e, n)); }
+  private:
 
   public:
     // Engine::new(rc)

@@ -66,6 +66,7 @@ struct rb_engine {
     rb_uniforms uniforms{};          // as handed over (before count patch-up)
     rb_progressive prh{};            // gpu_wrapper.rs:19-53
     bool iter_initialized = false;   // RaytracerFrameIterator::initialized (lib.rs:131)
+    uint32_t iter_passes_per_frame = 1;  // rb_iter_set_passes_per_frame (1 = the reference's one frame per pass)
 
     // element counts = what arrayLength() / the patched uniforms see
     uint32_t n_spheres = 0, n_lights = 0, n_meshes = 0, n_nodes = 0, n_indices = 0, n_tris = 0, n_uvs = 0,
@@ -847,15 +848,24 @@ int rb_iter_next(rb_engine* e, uint8_t* rgba_out) {
         if (rc) return rc;
         e->iter_initialized = true;
     }
-    rc = dispatch(e, e->prh.current_pass, 1);  // lib.rs:200-203
+    const uint32_t left = e->prh.total_passes - e->prh.current_pass;
+    const uint32_t n = std::min(std::max(e->iter_passes_per_frame, 1u), left);
+    rc = dispatch(e, e->prh.current_pass, n);  // lib.rs:200-203 (n = 1 there)
     if (rc) return rc;
     rc = read_rgba(e, rgba_out);  // lib.rs:205
     if (rc) return rc;
-    e->prh.current_pass += 1;  // lib.rs:213
+    e->prh.current_pass += n;  // lib.rs:213
     return accumulate_timing(e);
 }
 
 void rb_iter_destroy(rb_engine* e) { (void)e; }  // lib.rs:231-233: logs only
+
+int rb_iter_set_passes_per_frame(rb_engine* e, uint32_t n) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->iter_passes_per_frame = n;
+    return RB_OK;
+}
 
 int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height) {
     if (!e) return RB_ERR_NULL_ARGUMENT;

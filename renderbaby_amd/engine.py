@@ -235,10 +235,12 @@ class Engine:
         self._check(self._lib.rb_render(self._h, out.ctypes.data))
         return Frame(w, h, out)
 
-    def frame_iterator(self, rc: RenderConfig) -> "FrameIterator":
+    def frame_iterator(self, rc: RenderConfig, passes_per_frame: int = 1) -> "FrameIterator":
+        """``passes_per_frame`` > 1 (extension): one frame per that many samples instead of per sample."""
         cfg, keep = rc.to_c()
         self._check(self._lib.rb_iter_begin(self._h, C.byref(cfg)))
         del keep
+        self._check(self._lib.rb_iter_set_passes_per_frame(self._h, passes_per_frame))
         return FrameIterator(self)
 
     # ---- lower-level control (bench, tests, multi-GPU)

@@ -191,3 +191,23 @@ def test_frame_contract():
     px = np.array([[_oracle.color_map(mapped[y, x]) for x in range(20)] for y in range(12)], dtype=np.uint32)
     assert np.array_equal(f.pixels[..., 0], (px & 255).astype(np.uint8)[:, ::-1])
     e.close()
+
+
+def test_iterator_delivering_every_n_passes():
+    # extension (rb_iter_set_passes_per_frame): one frame per n samples; the frames are the
+    # reference's frames n-1, 2n-1, ... and the last one
+    s = scenes.cornell(40, 24, 7, 4)
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc)
+    it = eng.frame_iterator(rc, passes_per_frame=3)
+    frames = [f.pixels.copy() for f in it]
+    assert len(frames) == 3                                   # 3 + 3 + 1 samples
+    for frame, upto in zip(frames, (3, 6, 7)):
+        assert np.array_equal(frame, _oracle.render(s, 0, upto)[2]), upto
+    with pytest.raises(Exception) as ei:
+        it.next()
+    assert "No more frames available" in str(ei.value)
+    # back to one frame per pass
+    it = eng.frame_iterator(RenderConfig.from_scene(s, create=False))
+    assert len([1 for _ in it]) == 7
+    eng.close()

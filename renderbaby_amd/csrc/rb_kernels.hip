@@ -522,6 +522,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
     pt.depth = 0;
     FastWalk<STATS> w;
     w.begin(p, mk(0, 0, 0), mk(0, 0, 1));
+#ifdef RB_FAST_PROFILE  // -DRB_FAST_PROFILE: pass occupancy instead of the work counters (tools/ab.sh, RB_PRINT=1)
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     for (;;) {
         // ---- (1) hand items to idle lanes (same scheme as k_trace)
@@ -591,6 +594,11 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
             const bool at_node = state == TRAV && !w.at_leaf();
             const bool at_leaf = state == TRAV && w.at_leaf();
             const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+#ifdef RB_FAST_PROFILE
+            if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
+                if (n_leaf) { prof[2]++; prof[3] += n_leaf; } else { prof[0]++; prof[1] += n_node; }
+            } else { prof[0]++; prof[1] += n_node; }
+#endif
             if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
                 if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, tl)) state = FINISH;
                 if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
@@ -600,6 +608,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
         }
 
+#ifdef RB_FAST_PROFILE
+        { const uint32_t nf = (uint32_t)__popcll(__ballot(state == FINISH)); if (nf) { prof[4]++; prof[5] += nf; } }
+#endif
         // ---- (4) finished walks: ground, spheres, lights, shading, next ray
         if (state == FINISH) {
             const bool alive = segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
@@ -613,6 +624,10 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
         }
     }
     flush_tally<STATS>(tl, p.counters);
+#ifdef RB_FAST_PROFILE
+    // node passes, lanes in them, leaf passes, lanes in them, finish passes -> the five STATS counter slots
+    if (lane == 0u) for (int i = 0; i < 5; i++) atomicAdd(&p.counters[2 + i], prof[i]);
+#endif
 }
 
 // The sphere tree (scenes with more than 64 spheres, BASELINE C4) stepped the same way: in the

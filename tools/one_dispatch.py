@@ -21,6 +21,6 @@ eng = Engine.new(rc, kernel=kern, fast_bvh=bool(int(os.environ.get('RB_FAST', '0
 for _ in range(reps):
     eng.reset_stats(); eng.clear(); eng.dispatch(0, spp); eng.sync()
 st = eng.stats()
-print(st) if os.environ.get("RB_STATS") else None
+print(st) if (os.environ.get("RB_STATS") or os.environ.get("RB_PRINT")) else None
 print(w, spp, "kernel", kern, eng.last_kernel_name(), "ms", eng.last_dispatch_ms(), "segments", st["segments"], "Mseg/s", st["segments"] / eng.last_dispatch_ms() / 1e3)
 eng.close()

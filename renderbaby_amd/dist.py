@@ -97,7 +97,9 @@ class ShardedRenderer:
         if self.world == 1:
             return self.local
         import torch.distributed as dist
-        src = self.local.cpu() if self.host_gather else self.local
+        # the rows live in the library's own allocation; hand the collective a torch-owned copy (1 MB per
+        # rank) so nothing depends on how RCCL treats memory it did not see allocated
+        src = self.local.cpu() if self.host_gather else self.local.clone()
         dist.gather(src, self.gather_list, dst=0)
         if self.rank == 0:
             return assemble(self.gather_list, self.height, self.stripe_rows)

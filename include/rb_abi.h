@@ -231,9 +231,11 @@ enum {
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
     RB_FLAG_FAST_BVH = 4u, /* opt-in: walk the library's own SAH tree over the triangles (culling, near-first)
                               and accept a hit only if the reference's traversal would have tested it */
-    RB_FLAG_DEVICE_BVH = 8u /* with RB_FLAG_FAST_BVH: build that tree on the GPU (Morton order, LBVH) instead of
-                               on the host (binned SAH): milliseconds instead of ~0.5 s per million triangles, a
-                               somewhat slower walk, the same frames */
+    RB_FLAG_DEVICE_BVH = 8u, /* with RB_FLAG_FAST_BVH: build that tree on the GPU (Morton order + locally-ordered
+                                clustering) instead of on the host (binned SAH): milliseconds instead of ~0.5 s per
+                                million triangles, the same frames */
+    RB_FLAG_DEVICE_LBVH = 16u /* with RB_FLAG_DEVICE_BVH: plain LBVH instead of the clustering (ablation: faster
+                                 build, slower walk) */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.

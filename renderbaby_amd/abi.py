@@ -64,6 +64,7 @@ FLAG_STATS = 1
 FLAG_NO_SPHERE_BVH = 2
 FLAG_FAST_BVH = 4
 FLAG_DEVICE_BVH = 8
+FLAG_DEVICE_LBVH = 16
 
 
 class Field(C.Structure):

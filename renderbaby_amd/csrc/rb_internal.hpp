@@ -62,7 +62,8 @@ struct DeviceTreeInfo {
     float bmin[3], bmax[3];
 };
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream);
+                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream,
+                          bool plain_lbvh);
 
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {

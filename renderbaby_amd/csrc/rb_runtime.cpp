@@ -432,7 +432,8 @@ int ensure_prepared(rb_engine* e) {
                 HIP_TRY(e, e->fast_slots.resize(n));
                 rb::DeviceTreeInfo info{};
                 rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
-                                               e->fast_slots.ptr, &info, e->stream);
+                                               e->fast_slots.ptr, &info, e->stream,
+                                               (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
                 if (rc) return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
                 // a tree deeper than the LDS stack spills to a global scratch column per lane, which only the
                 // persistent kernels (bounded grid) get; otherwise use the depth-limited host builder
@@ -453,7 +454,7 @@ int ensure_prepared(rb_engine* e) {
                         ft.bmax[i] = info.bmax[i];
                     }
                     built = true;
-                    e->fast_builder = "device-lbvh";
+                    e->fast_builder = (e->opt.flags & RB_FLAG_DEVICE_LBVH) ? "device-lbvh" : "device-ploc";
                 }
             }
         }

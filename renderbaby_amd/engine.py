@@ -169,7 +169,7 @@ class Engine:
     """``engine_pathtracer::Engine`` for the HIP backend."""
 
     def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
-                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False):
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False, device_lbvh=False):
         self._lib = load()
         cfg, keep = rc.to_c()
         opt = abi.Options()
@@ -178,7 +178,7 @@ class Engine:
         opt.passes_per_launch = passes_per_launch
         opt.kernel = kernel
         opt.flags = (abi.FLAG_STATS if stats else 0) | (abi.FLAG_NO_SPHERE_BVH if no_sphere_bvh else 0) \
-            | (abi.FLAG_FAST_BVH if (fast_bvh or device_bvh) else 0) | (abi.FLAG_DEVICE_BVH if device_bvh else 0)
+            | (abi.FLAG_FAST_BVH if (fast_bvh or device_bvh or device_lbvh) else 0) | (abi.FLAG_DEVICE_BVH if (device_bvh or device_lbvh) else 0) | (abi.FLAG_DEVICE_LBVH if device_lbvh else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[3] = 1 if no_leaf_stepping else 0   # ablation: per-segment traversal for multi-node trees

@@ -75,13 +75,13 @@ def test_c3_fast_bvh_equals_reference_walk_on_the_full_frame():
     s = scenes.mesh_scene(112, 112, 1920, 1080, 8, 5)
     rc = RenderConfig.from_scene(s)
     out = {}
-    for mode in ("exact", "host-sah", "device-lbvh"):
-        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-lbvh"))
+    for mode in ("exact", "host-sah", "device-ploc", "device-lbvh"):
+        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=mode.startswith("device"), device_lbvh=(mode == "device-lbvh"))
         e.render(rc)
         out[mode] = (e.read_accumulation(), e.stats()["segments"])
         assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
         e.close()
-    for mode in ("host-sah", "device-lbvh"):
+    for mode in ("host-sah", "device-ploc", "device-lbvh"):
         diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
         assert out["exact"][1] == out[mode][1]

@@ -175,6 +175,7 @@ def _scene_for(which):
 @pytest.mark.parametrize("which,kw,kernel_name", [
     ("mesh", dict(), "k_trace_bvh_lds"), ("mesh", dict(lds_mode=1), "k_trace_bvh"),
     ("mesh", dict(fast_bvh=True), "k_trace_fast"), ("mesh", dict(device_bvh=True), "k_trace_fast"),
+    ("mesh", dict(device_lbvh=True), "k_trace_fast"),
     ("spheres", dict(), "k_trace_sph"), ("spheres", dict(no_leaf_stepping=True), "k_trace")])
 def test_stepped_kernels_under_chunking_sharding_and_the_iterator(which, kw, kernel_name):
     # the persistent, stepped kernels keep per-lane walk state across passes; cutting the work into
@@ -245,15 +246,16 @@ def test_fast_bvh_reproduces_the_reference_walk(grid, w, h, spp, color_hash):
     assert st["tris_tested"] < o_st["tris_tested"] / 4  # it must actually be the fast walk
 
 
-@pytest.mark.parametrize("grid,w,h,spp,builder", [(24, 64, 40, 4, "device-lbvh"), (112, 96, 54, 2, "device-lbvh"),
-                                                  (12, 64, 40, 2, "host-sah")])
-def test_device_built_tree_reproduces_the_reference_walk(grid, w, h, spp, builder):
-    # RB_FLAG_DEVICE_BVH: the fast walk's tree built on the GPU (Morton order + LBVH).  The tree only
-    # steers the walk, so the frame is still the reference walk's, bit for bit.  Below 1024 triangles
-    # the host builder is used.
+@pytest.mark.parametrize("grid,w,h,spp,lbvh,builder", [
+    (24, 64, 40, 4, False, "device-ploc"), (112, 96, 54, 2, False, "device-ploc"), (24, 64, 40, 4, True, "device-lbvh"),
+    (112, 96, 54, 2, True, "device-lbvh"), (12, 64, 40, 2, False, "host-sah")])
+def test_device_built_tree_reproduces_the_reference_walk(grid, w, h, spp, lbvh, builder):
+    # RB_FLAG_DEVICE_BVH: the fast walk's tree built on the GPU (Morton order + locally-ordered
+    # clustering, or plain LBVH with RB_FLAG_DEVICE_LBVH).  The tree only steers the walk, so the frame
+    # is still the reference walk's, bit for bit.  Below 1024 triangles the host builder is used.
     s = scenes.mesh_scene(grid, grid, w, h, spp, 5, seed=7)
     rc = RenderConfig.from_scene(s)
-    eng = Engine.new(rc, stats=True, device_bvh=True)
+    eng = Engine.new(rc, stats=True, device_bvh=True, device_lbvh=lbvh)
     frame = eng.render(rc)
     acc, st = eng.read_accumulation(), eng.stats()
     name, ms = eng.fast_bvh_builder()

@@ -333,13 +333,14 @@ def test_reference_lamp_scene_fixture_matches_the_rscn_file():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "host-sah", "device-lbvh"])
+@pytest.mark.parametrize("mode", ["exact", "host-sah", "device-ploc", "device-lbvh"])
 def test_reference_lamp_scene_bit_exact_on_gpu(mode):
     from renderbaby_amd import Engine, RenderConfig
     s = _refscenes.ref_lamp(width=96, height=96, spp=2)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
     rc = RenderConfig.from_scene(s)
-    e = Engine.new(rc, stats=True, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-lbvh"))
+    e = Engine.new(rc, stats=True, fast_bvh=(mode != "exact"), device_bvh=mode.startswith("device"),
+                   device_lbvh=(mode == "device-lbvh"))
     f = e.render(rc)
     acc, st = e.read_accumulation(), e.stats()
     assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)

@@ -14,6 +14,10 @@ fixtures can be fed to the kernels with the reference's conventions.
   one sub-mesh per material index, GPUTriangles, BVH.  The reference iterates a ``HashMap`` of
   sub-meshes, so their order is unspecified there; here they are sorted by material index.
 
+* ``read_scene_description`` / ``build_scene`` / ``load_scene`` -- scene_importer.rs:21-229,
+  render_scene.rs:47-210: ``.json`` / ``.rscn`` scene files, object transforms, textures.
+* ``export_scene`` / ``export_png`` -- scene_exporter.rs:14-254, img_export.rs:5-18.
+
 Host-side Python on purpose: none of this is per-ray work.
 """
 from dataclasses import dataclass, field
@@ -349,6 +353,7 @@ def parse_scene_file(text: str) -> dict:
         "background_color": _color(j["background_color"], "background_color"),
         "camera": {
             "position": _vec3(cam["position"], "camera.position"), "look_at": _vec3(cam["look_at"], "camera.look_at"),
+            "up": _vec3(cam["up"], "camera.up"),
             "pane_distance": float(cam["pane_distance"]), "pane_width": float(cam["pane_width"]),
             "resolution": (int(cam["resolution"]["x"]), int(cam["resolution"]["y"])),
         },
@@ -365,7 +370,8 @@ def parse_scene_file(text: str) -> dict:
             if k not in l:
                 raise SceneFileError(f"JSON does not comply with Schema: lights[{i}].{k}")
         out["lights"].append({"name": l["name"], "position": _vec3(l["position"], "position"),
-                              "luminosity": float(l["luminosity"]), "color": _color(l["color"], "color")})
+                              "luminosity": float(l["luminosity"]), "color": _color(l["color"], "color"),
+                              "rotation": _vec3(l["rotation"], "rotation") if l.get("rotation") else [0.0, 0.0, 0.0]})
     misc = j.get("misc") or {}
     for i, s in enumerate(misc.get("spheres") or []):
         for k in ("center", "radius", "color"):
@@ -405,14 +411,11 @@ def _resolve(p: str, base: str, included_root: Optional[str]) -> str:
     return p if os.path.isabs(p) else os.path.join(base, p)
 
 
-def load_scene(path: str, json_string: Optional[str] = None, extract_dir: Optional[str] = None, max_depth=5,
-               ground_enabled=1, ground_height=-1.0, checkerboard_enabled=1, total_samples=None, bvh_builder=None,
-               included_root: Optional[str] = None):
-    """Scene::load_scene_from_path (render_scene.rs:47-77,186-210) + parse_scene
-    (scene_importer.rs:140-229) + generate_full_render_command_builder: a ``.json`` scene file or a
-    ``.rscn`` archive (zip with a scene.json and its assets) -> flat ``scenes.Scene`` ready for
-    ``RenderConfig.from_scene``.  Render parameters that are not part of the file (ground,
-    checkerboard, max depth) default to ``RenderParameter::default()`` (render_parameter.rs:17-33)."""
+def read_scene_description(path: str, json_string: Optional[str] = None, extract_dir: Optional[str] = None,
+                           included_root: Optional[str] = None) -> dict:
+    """parse_scene (scene_importer.rs:140-229): the scene file as a description (what ``SceneFile``
+    holds), with every object's path resolved (``abs_path``) and ``is_rscn`` / ``base_dir`` noted.
+    ``.rscn`` archives are unpacked into ``extract_dir`` (a fresh temporary directory by default)."""
     is_rscn = path.lower().endswith(".rscn")
     if is_rscn:
         import tempfile
@@ -439,11 +442,33 @@ def load_scene(path: str, json_string: Optional[str] = None, extract_dir: Option
             text = f.read()
         base = os.path.dirname(os.path.abspath(path))
     sf = parse_scene_file(text)
+    sf["is_rscn"], sf["base_dir"] = is_rscn, base
+    for o in sf["objects"]:
+        o["abs_path"] = os.path.abspath(_resolve(o["path"], base, included_root))
+    return sf
 
+
+def load_scene(path: str, json_string: Optional[str] = None, extract_dir: Optional[str] = None, max_depth=5,
+               ground_enabled=1, ground_height=-1.0, checkerboard_enabled=1, total_samples=None, bvh_builder=None,
+               included_root: Optional[str] = None):
+    """Scene::load_scene_from_path (render_scene.rs:47-77,186-210) + parse_scene
+    (scene_importer.rs:140-229) + generate_full_render_command_builder: a ``.json`` scene file or a
+    ``.rscn`` archive (zip with a scene.json and its assets) -> flat ``scenes.Scene`` ready for
+    ``RenderConfig.from_scene``.  Render parameters that are not part of the file (ground,
+    checkerboard, max depth) default to ``RenderParameter::default()`` (render_parameter.rs:17-33)."""
+    sf = read_scene_description(path, json_string, extract_dir, included_root)
+    return build_scene(sf, max_depth, ground_enabled, ground_height, checkerboard_enabled, total_samples, bvh_builder,
+                       included_root)
+
+
+def build_scene(sf: dict, max_depth=5, ground_enabled=1, ground_height=-1.0, checkerboard_enabled=1, total_samples=None,
+                bvh_builder=None, included_root: Optional[str] = None):
+    """A scene description -> flat ``scenes.Scene`` (meshes loaded and transformed, adapter rules)."""
+    is_rscn, base = sf["is_rscn"], sf["base_dir"]
     tex_paths: set = set()
     meshes = []
     for o in sf["objects"]:
-        m = load_obj_file(_resolve(o["path"], base, included_root), tex_paths)
+        m = load_obj_file(o["abs_path"], tex_paths)
         meshes.append(transform_mesh(m, o["scale"][0], o["rotation"], o["translation"]))
     # texture indices follow the sorted paths (texture_loader.rs:44-49)
     tex_order = sorted(tex_paths)
@@ -484,6 +509,106 @@ def load_scene(path: str, json_string: Optional[str] = None, extract_dir: Option
         groups += g
         uv_groups += uvg
     return scenes._finish(sf["scene_name"], u, spheres, lights, groups, uv_groups, textures, bvh_builder=bvh_builder)
+
+
+def _copy_obj_dependencies(src_obj: str, dest_obj: str) -> None:
+    """copy_obj_dependencies / resolve_and_copy (scene_exporter.rs:257-330): every ``mtllib`` next to the
+    OBJ, and from each MTL every ``map_*`` / ``bump`` file, keeping the relative paths."""
+    import shutil
+
+    def copy_rel(ref_src, ref_dest, rel, is_mtl):
+        sp, dp = os.path.join(os.path.dirname(ref_src), rel), os.path.join(os.path.dirname(ref_dest), rel)
+        if not os.path.exists(sp):
+            return
+        os.makedirs(os.path.dirname(dp), exist_ok=True)
+        if not os.path.exists(dp):
+            shutil.copyfile(sp, dp)
+        if is_mtl:
+            with open(sp, "r", errors="replace") as f:
+                for line in f:
+                    t = line.strip()
+                    if (t.startswith("map_") or t.startswith("bump")) and len(t.split()) > 1:
+                        copy_rel(sp, dp, t.split()[-1], False)
+
+    with open(src_obj, "r", errors="replace") as f:
+        for line in f:
+            t = line.strip()
+            if t.startswith("mtllib") and len(t.split()) > 1:
+                copy_rel(src_obj, dest_obj, t.split()[1], True)
+
+
+def export_scene(sf: dict, path: str, export_misc: bool = False) -> None:
+    """serialize_scene (scene_exporter.rs:14-254): write a scene description as a ``.json`` file
+    (object paths relative to it where possible) or as a ``.rscn`` archive -- ``scene/scene.json``
+    plus copies of every OBJ with its MTL and texture files under ``scene/obj/``.  ``misc`` (spheres,
+    ray_samples, hash_color) is only written with ``export_misc`` (it goes beyond the rscn standard)."""
+    import shutil
+    import tempfile
+    is_rscn = path.lower().endswith(".rscn")
+    staging = tempfile.mkdtemp(prefix="renderbaby_export_") if is_rscn else None
+    base_dir = os.path.join(staging, "scene") if is_rscn else os.path.dirname(os.path.abspath(path))
+    if is_rscn:
+        os.makedirs(os.path.join(base_dir, "obj"), exist_ok=True)
+
+    def v3(v):
+        return {"x": float(v[0]), "y": float(v[1]), "z": float(v[2])}
+
+    def rgb(c):
+        return {"r": float(c[0]), "g": float(c[1]), "b": float(c[2])}
+
+    objects = []
+    for o in sf["objects"]:
+        src = o.get("abs_path") or o["path"]
+        if is_rscn:
+            rel = os.path.join("obj", os.path.basename(src))
+            dest = os.path.join(base_dir, rel)
+            if os.path.exists(src):
+                shutil.copyfile(src, dest)
+                _copy_obj_dependencies(src, dest)
+            written = rel.replace(os.sep, "/")
+        else:
+            a = os.path.abspath(src)
+            parent = os.path.dirname(base_dir)
+            if a.startswith(base_dir + os.sep):
+                written = os.path.relpath(a, base_dir)
+            elif a.startswith(parent + os.sep):
+                written = os.path.join("..", os.path.relpath(a, parent))
+            else:
+                written = a
+        objects.append({"name": o["name"], "path": written, "scale": v3(o["scale"]), "translation": v3(o["translation"]),
+                        "rotation": v3(o["rotation"])})
+    cam = sf["camera"]
+    out = {
+        "scene_name": sf["scene_name"],
+        "objects": objects,
+        "lights": [{"name": l["name"], "type": "point", "position": v3(l["position"]), "luminosity": float(l["luminosity"]),
+                    "color": rgb(l["color"]), "rotation": v3(l.get("rotation", (0, 0, 0)))} for l in sf["lights"]],
+        "camera": {"position": v3(cam["position"]), "look_at": v3(cam["look_at"]), "up": v3(cam.get("up", (0, 1, 0))),
+                   "pane_distance": float(cam["pane_distance"]), "pane_width": float(cam["pane_width"]),
+                   "resolution": {"x": int(cam["resolution"][0]), "y": int(cam["resolution"][1])}},
+        "background_color": rgb(sf["background_color"]),
+    }
+    if export_misc:
+        spheres = []
+        for sp in sf.get("spheres", []):
+            d = {"center": v3(sp["center"]), "radius": float(sp["radius"]), "color": rgb(sp["color"]), "name": "Sphere",
+                 "scale": v3((1, 1, 1)), "translation": v3((0, 0, 0)), "rotation": v3((0, 0, 0))}
+            if sp.get("material") is not None:
+                d["material"] = sp["material"]
+            spheres.append(d)
+        out["misc"] = {"spheres": spheres,
+                       "ray_samples": int(sf["ray_samples"]) if sf.get("ray_samples") is not None else 1,
+                       "hash_color": bool(sf["hash_color"]) if sf.get("hash_color") is not None else True}
+    json_path = os.path.join(base_dir, "scene.json") if is_rscn else path
+    with open(json_path, "w") as f:
+        json.dump(out, f, indent=2)
+    if is_rscn:   # FileManager::zip_scene: the staging directory's content, i.e. scene/...
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+            for d, _, files in sorted(os.walk(staging)):
+                for name in sorted(files):
+                    full = os.path.join(d, name)
+                    z.write(full, os.path.relpath(full, staging).replace(os.sep, "/"))
+        shutil.rmtree(staging, ignore_errors=True)
 
 
 def export_png(path: str, frame) -> None:

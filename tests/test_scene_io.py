@@ -349,3 +349,80 @@ def test_reference_lamp_scene_bit_exact_on_gpu(mode):
     assert st["segments"] == o_st["segments"]
     if mode == "exact":
         assert {k: st[k] for k in _oracle.STAT_KEYS} == o_st
+
+
+# ------------------------------------------------------------------ export (scene_io/tests.rs)
+def _description(tmp_path, name="JsonTest", with_mesh=False, misc=None):
+    """create_test_scene (tests.rs:14-42): a red sphere, a light, a camera; optionally the cube mesh."""
+    d = {"scene_name": name, "objects": [], "is_rscn": False, "base_dir": str(tmp_path),
+         "lights": [{"name": "TestLight", "position": [10.0, 10.0, 10.0], "luminosity": 100.0, "color": [1.0, 1.0, 1.0],
+                     "rotation": [0.0, 0.0, 0.0]}],
+         "camera": {"position": [0.0, 0.0, -10.0], "look_at": [1.0, 1.0, 1.0], "up": [0.0, 1.0, 0.0],
+                    "pane_distance": 35.0, "pane_width": 36.0, "resolution": (400, 300)},
+         "background_color": [0.5, 0.7, 1.0],
+         "spheres": [{"center": [1.0, 2.0, 3.0], "radius": 1.5, "color": [1.0, 0.0, 0.0], "material": {"preset": "mirror"}}],
+         "ray_samples": None, "hash_color": None}
+    if misc:
+        d.update(misc)
+    if with_mesh:
+        src = tmp_path / "assets"
+        _write_scene_dir(str(src))
+        d["objects"].append({"name": "cube", "path": "obj/cube.obj", "abs_path": str(src / "obj" / "cube.obj"),
+                             "scale": [1.0, 1.0, 1.0], "translation": [0.0, 0.0, 0.0], "rotation": [0.0, 0.0, 0.0]})
+    return d
+
+
+def test_json_export_import_integrity(tmp_path):          # tests.rs:59-80
+    p = str(tmp_path / "test_scene.json")
+    scene_io.export_scene(_description(tmp_path), p)
+    back = scene_io.read_scene_description(p)
+    assert back["scene_name"] == "JsonTest"
+    assert back["spheres"] == []                          # spheres are misc: not exported by default
+    assert back["lights"][0]["name"] == "TestLight" and back["lights"][0]["luminosity"] == 100.0
+    assert back["camera"]["position"] == [0.0, 0.0, -10.0] and back["camera"]["resolution"] == (400, 300)
+
+
+def test_rscn_export_import_with_mesh_and_mtl(tmp_path):  # tests.rs:82-150, 265-312
+    p = str(tmp_path / "test_bundle.rscn")
+    d = _description(tmp_path, "RscnTest", with_mesh=True)
+    scene_io.export_scene(d, p)
+    with zipfile.ZipFile(p) as z:
+        names = set(z.namelist())
+    assert {"scene/scene.json", "scene/obj/cube.obj", "scene/obj/cube.mtl", "scene/obj/skin.png"} <= names
+    back = scene_io.read_scene_description(p, extract_dir=str(tmp_path / "x"))
+    assert back["scene_name"] == "RscnTest" and len(back["objects"]) == 1 and back["objects"][0]["name"] == "cube"
+    ap = back["objects"][0]["abs_path"]
+    assert os.path.isabs(ap) and os.path.isfile(ap) and ap != d["objects"][0]["abs_path"]
+    flat = scene_io.build_scene(back)
+    assert len(flat.bvh_triangles) == 12 and len(flat.textures) == 1
+    assert flat.uniforms[0]["color_hash_enabled"] == 0    # tests.rs:243-263: rscn import disables colour hash
+    # idempotency (tests.rs:181-212): importing twice gives equivalent scenes
+    again = scene_io.build_scene(scene_io.read_scene_description(p, extract_dir=str(tmp_path / "y")))
+    assert np.array_equal(flat.bvh_triangles, again.bvh_triangles) and len(flat.lights) == len(again.lights)
+
+
+def test_export_import_misc_data(tmp_path):               # tests.rs:314-381
+    p = str(tmp_path / "misc.json")
+    d = _description(tmp_path, "Test Scene", misc={"ray_samples": 10, "hash_color": False})
+    scene_io.export_scene(d, p, export_misc=True)
+    back = scene_io.read_scene_description(p)
+    assert len(back["spheres"]) == 1 and back["spheres"][0]["center"] == [1.0, 2.0, 3.0] and back["spheres"][0]["radius"] == 1.5
+    assert back["ray_samples"] == 10 and back["hash_color"] is False
+    p2 = str(tmp_path / "no_misc.json")
+    scene_io.export_scene(d, p2, export_misc=False)
+    back = scene_io.read_scene_description(p2)
+    assert back["spheres"] == [] and back["ray_samples"] is None and back["hash_color"] is None
+    flat = scene_io.build_scene(back)
+    assert flat.uniforms[0]["total_samples"] == 1 and flat.uniforms[0]["color_hash_enabled"] == 1   # the defaults
+
+
+def test_json_export_writes_relative_object_paths(tmp_path):   # scene_exporter.rs:125-147
+    d = _description(tmp_path, with_mesh=True)
+    inside = str(tmp_path / "assets" / "scene_out.json")
+    scene_io.export_scene(d, inside)
+    assert json.load(open(inside))["objects"][0]["path"] == os.path.join("obj", "cube.obj")
+    os.makedirs(tmp_path / "sibling")
+    sibling = str(tmp_path / "sibling" / "scene_out.json")
+    scene_io.export_scene(d, sibling)
+    assert json.load(open(sibling))["objects"][0]["path"] == os.path.join("..", "assets", "obj", "cube.obj")
+    assert len(scene_io.load_scene(sibling).bvh_triangles) == 12

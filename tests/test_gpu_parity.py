@@ -310,6 +310,21 @@ def test_degenerate_frame_sizes(w, h):
         assert st["segments"] == o_st["segments"]
 
 
+@pytest.mark.parametrize("which,kw", [("mesh", dict()), ("mesh", dict(lds_mode=1)), ("mesh", dict(fast_bvh=True)),
+                                      ("mesh", dict(device_bvh=True)), ("spheres", dict())])
+@pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 2, 3), (3, 1, 1, 1), (2, 7, 2, 0), (9, 5, 1, 16)])
+def test_stepped_kernels_on_degenerate_frames(which, kw, w, h, spp, depth):
+    # one-pixel axes (inf / NaN primary directions), a single sample, depth 0 and a depth beyond any
+    # path through the stepped kernels: same bits and same counters as the oracle
+    base = _scene_for(which)
+    s = base.with_params(width=w, height=h, spp=spp, max_depth=depth)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=True, **kw)
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32))
+    assert np.array_equal(frame.pixels, o_rgba)
+    assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"]
+
+
 def test_zero_samples_and_zero_depth():
     s = scenes.cornell(8, 4, 0, 4)  # total_samples = 0: no passes; the reference returns the cleared buffers
     rc = RenderConfig.from_scene(s)

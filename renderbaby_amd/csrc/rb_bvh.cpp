@@ -13,7 +13,9 @@
 #include "rb_internal.hpp"
 
 #include <algorithm>
+#include <future>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -242,6 +244,8 @@ struct FBuilder {
     std::vector<SphereNode>& nodes;
     uint32_t limit;
     uint32_t max_depth = 0;
+    uint32_t par_levels = 0;   // levels below this call that may still fork a thread
+    static constexpr size_t kParallelCount = 16384;
 
     void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
         for (int a = 0; a < 3; ++a) {
@@ -357,8 +361,34 @@ struct FBuilder {
         SphereNode n;
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
-        n.left = build(first, mid - first, depth + 1);
-        n.right = build(mid, first + count - mid, depth + 1);
+        if (count >= kParallelCount && par_levels > 0u) {
+            // big subtrees: the two halves touch disjoint ranges of `items`, so the left one is built
+            // by another thread into its own node array; appending left then right with their
+            // indices shifted reproduces the sequential (pre-order) numbering exactly
+            std::vector<SphereNode> lv, rv;
+            FBuilder lb{bmn, bmx, e1e2, items, lv, limit, 0, par_levels - 1u};
+            FBuilder rb{bmn, bmx, e1e2, items, rv, limit, 0, par_levels - 1u};
+            auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
+            uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
+            uint32_t lref = fut.get();
+            auto append = [&](const std::vector<SphereNode>& v, uint32_t& ref) {
+                const uint32_t off = static_cast<uint32_t>(nodes.size());
+                for (SphereNode c : v) {
+                    if (!(c.left & 0x80000000u)) c.left += off;
+                    if (!(c.right & 0x80000000u)) c.right += off;
+                    nodes.push_back(c);
+                }
+                if (!(ref & 0x80000000u)) ref += off;
+            };
+            append(lv, lref);
+            append(rv, rref);
+            n.left = lref;
+            n.right = rref;
+            max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
+        } else {
+            n.left = build(first, mid - first, depth + 1);
+            n.right = build(mid, first + count - mid, depth + 1);
+        }
         // largest |e1|*|e2| below each child: scales the per-ray inflation of that child's box
         const float al = amax(first, mid - first), ar = amax(mid, first + count - mid);
         std::memcpy(&n._pad0, &al, 4);
@@ -428,7 +458,10 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     }
     std::vector<uint32_t> items(n);
     for (size_t i = 0; i < n; ++i) items[i] = static_cast<uint32_t>(i);
-    FBuilder fb{bmn, bmx, e1e2, items, out.nodes, stack_limit};
+    // up to 64 threads at the sixth level; RB_HOST_BUILD_SEQUENTIAL=1 (debug) builds on one thread -- the
+    // tree is the same either way (tests/test_gpu_parity.py compares the walk's counters)
+    const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
+    FBuilder fb{bmn, bmx, e1e2, items, out.nodes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
     out.slots.resize(n);

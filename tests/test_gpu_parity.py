@@ -269,6 +269,20 @@ def test_device_built_tree_reproduces_the_reference_walk(grid, w, h, spp, lbvh, 
     assert st["tris_tested"] < o_st["tris_tested"] / 4
 
 
+def test_threaded_host_tree_build_is_deterministic(monkeypatch):
+    # the host SAH builder forks big subtrees onto threads; the tree must be the one the sequential
+    # build makes: same frame, and the same node / triangle counters in the walk
+    s = scenes.mesh_scene(160, 160, 64, 40, 2, 5, seed=5)       # 102 402 triangles: forks at several levels
+    out = []
+    for seq in ("0", "1"):
+        monkeypatch.setenv("RB_HOST_BUILD_SEQUENTIAL", seq)
+        frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=True, fast_bvh=True)
+        out.append((acc, st))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    for k in ("segments", "nodes_popped", "tris_tested", "mesh_hits"):
+        assert out[0][1][k] == out[1][1][k], k
+
+
 def test_fast_reciprocal_and_sqrt_are_exhaustively_exact():
     # the kernels replace the 12-instruction IEEE divide by rcp + Newton/FMA steps where the
     # operands allow; correctness is a property of the significand, so it is checked for ALL

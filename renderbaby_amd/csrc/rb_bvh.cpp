@@ -149,11 +149,26 @@ bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_st
 // discriminant, runs the reference's exact intersect_sphere on every candidate and
 // breaks ties by the lower original index -- the winner of the linear scan.
 namespace {
+// Both two-box builders fork big subtrees onto threads: the halves touch disjoint ranges of the
+// item array, the left one is built into its own node array, and appending left then right with
+// their node indices shifted reproduces the sequential (pre-order) numbering exactly.
+constexpr size_t kParallelCount = 16384;
+inline void append_subtree(std::vector<SphereNode>& nodes, const std::vector<SphereNode>& v, uint32_t& ref) {
+    const uint32_t off = static_cast<uint32_t>(nodes.size());
+    for (SphereNode c : v) {
+        if (!(c.left & 0x80000000u)) c.left += off;
+        if (!(c.right & 0x80000000u)) c.right += off;
+        nodes.push_back(c);
+    }
+    if (!(ref & 0x80000000u)) ref += off;
+}
+
 struct SBuilder {
     const rb_sphere* sph;
     std::vector<uint32_t>& order;
     std::vector<SphereNode>& nodes;
     uint32_t max_depth = 0;
+    uint32_t par_levels = 0;   // levels below this call that may still fork a thread
 
     void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
         for (int a = 0; a < 3; ++a) {
@@ -192,8 +207,21 @@ struct SBuilder {
         SphereNode n;
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
-        n.left = build(first, mid - first, depth + 1);
-        n.right = build(mid, first + count - mid, depth + 1);
+        if (count >= kParallelCount && par_levels > 0u) {
+            std::vector<SphereNode> lv, rv;
+            SBuilder lb{sph, order, lv, 0, par_levels - 1u}, rb{sph, order, rv, 0, par_levels - 1u};
+            auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
+            uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
+            uint32_t lref = fut.get();
+            append_subtree(nodes, lv, lref);
+            append_subtree(nodes, rv, rref);
+            n.left = lref;
+            n.right = rref;
+            max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
+        } else {
+            n.left = build(first, mid - first, depth + 1);
+            n.right = build(mid, first + count - mid, depth + 1);
+        }
         n._pad0 = n._pad1 = 0;
         nodes[me] = n;
         return me;
@@ -207,7 +235,7 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
     nodes.clear();
     order.resize(n);
     for (size_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
-    SBuilder b{spheres, order, nodes};
+    SBuilder b{spheres, order, nodes, 0, 6u};
     b.bounds(0, n, bmin, bmax);
     *root_ref = n ? b.build(0, n, 1) : 0x80000000u;
     *depth = b.max_depth + 1;
@@ -245,7 +273,6 @@ struct FBuilder {
     uint32_t limit;
     uint32_t max_depth = 0;
     uint32_t par_levels = 0;   // levels below this call that may still fork a thread
-    static constexpr size_t kParallelCount = 16384;
 
     void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
         for (int a = 0; a < 3; ++a) {
@@ -362,26 +389,14 @@ struct FBuilder {
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
         if (count >= kParallelCount && par_levels > 0u) {
-            // big subtrees: the two halves touch disjoint ranges of `items`, so the left one is built
-            // by another thread into its own node array; appending left then right with their
-            // indices shifted reproduces the sequential (pre-order) numbering exactly
             std::vector<SphereNode> lv, rv;
             FBuilder lb{bmn, bmx, e1e2, items, lv, limit, 0, par_levels - 1u};
             FBuilder rb{bmn, bmx, e1e2, items, rv, limit, 0, par_levels - 1u};
             auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
             uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
             uint32_t lref = fut.get();
-            auto append = [&](const std::vector<SphereNode>& v, uint32_t& ref) {
-                const uint32_t off = static_cast<uint32_t>(nodes.size());
-                for (SphereNode c : v) {
-                    if (!(c.left & 0x80000000u)) c.left += off;
-                    if (!(c.right & 0x80000000u)) c.right += off;
-                    nodes.push_back(c);
-                }
-                if (!(ref & 0x80000000u)) ref += off;
-            };
-            append(lv, lref);
-            append(rv, rref);
+            append_subtree(nodes, lv, lref);
+            append_subtree(nodes, rv, rref);
             n.left = lref;
             n.right = rref;
             max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));

@@ -54,12 +54,16 @@ DEV bool near_zero(f3 v) {                                                // :46
 //  * the scan accepts `t > 0.001 && t < closest.t` in index order, i.e. the winner is the
 //    smallest t below the incoming closest_t, ties going to the lowest index: here
 //    `t < best || (t == best && id < best_id)`;
-//  * a subtree is skipped only if the ray misses its box inflated by m, or enters it beyond
-//    best_t.  m covers the rounding error of the reference's own arithmetic: its discriminant
+//  * a subtree is skipped only if the ray misses its box inflated by a margin, or enters it beyond
+//    best_t.  The margin covers the rounding error of the reference's own arithmetic: its discriminant
 //    hb^2 - a*(|oc|^2 - r^2) carries an absolute error <= 16 u a |oc|^2 (u = 2^-24), so a sphere
-//    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 D^2) from its centre and the
-//    reported t can be early by about the same amount; D = the farthest the ray origin can be
-//    from any sphere.  m = 3e-3 * D (> 2 * sqrt(1e-6) * D) bounds both.
+//    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 |oc|^2) from its centre and the
+//    reported t can be early by about the same amount.  For every sphere below a box, |oc| <= D =
+//    distance from the ray origin to the box's farthest corner; 3e-3 * D (> 2 * sqrt(1e-6) * D)
+//    bounds both.
+#ifndef RB_SPHERE_NODE_MARGIN
+#define RB_SPHERE_NODE_MARGIN 1
+#endif
 // Resumable (like FastWalk): the per-segment kernels run it to completion, k_trace_sph steps it.
 struct SphereWalk {
     f3 o, d, inv;
@@ -89,11 +93,22 @@ struct SphereWalk {
         cur = stack[sp * stride];
         return true;
     }
-    // slab test of a box inflated by m: visit unless missed or entered beyond `best`
-    // (comparisons are written so that a NaN means "visit")
+    // slab test of a box inflated by its own margin: visit unless missed or entered beyond `best`
+    // (comparisons are written so that a NaN means "visit").  The margin covers the rounding error of
+    // the reference's discriminant, which grows with |origin - centre|^2 of the sphere at hand: for the
+    // spheres below this box that distance is at most the distance to the box's farthest corner, so
+    // nearby subtrees get a margin far below the scene-wide one (RB_SPHERE_NODE_MARGIN=0 restores it).
     DEV bool entry(v4f lo, v4f hi, float& tn) const {
-        const f3 t0 = (mk(lo.x - m, lo.y - m, lo.z - m) - o) * inv;
-        const f3 t1 = (mk(hi.x + m, hi.y + m, hi.z + m) - o) * inv;
+        const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
+#if RB_SPHERE_NODE_MARGIN
+        const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
+        // v_sqrt_f32 is within 1 ulp; 3.001e-3 keeps the product above 3e-3 * the exact root
+        const float mm = 3.001e-3f * __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) + 1e-4f;
+#else
+        const float mm = m;
+#endif
+        const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
+        const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > best);

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ 
             info->bmax[a] = ord2f(bounds[3 + a]);
             d[a] = info->bmax[a] - info->bmin[a];
         }
-        info->margin = 1e-4f * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-6f;
+        info->margin = kFastSlabMargin * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-6f;
     }
 }
 
@@ -396,7 +396,7 @@ __global__ void k_ploc_finish(PlocClusters c, const uint32_t* __restrict__ bound
         info->bmax[a] = ord2f(bounds[3 + a]);
         d[a] = info->bmax[a] - info->bmin[a];
     }
-    info->margin = 1e-4f * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-6f;
+    info->margin = kFastSlabMargin * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-6f;
 }
 
 inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }

@@ -482,7 +482,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     out.slots.resize(n);
     for (size_t i = 0; i < n; ++i) out.slots[i] = slots[items[i]];
     const float dx = smx[0] - smn[0], dy = smx[1] - smn[1], dz = smx[2] - smn[2];
-    out.margin = 1e-4f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-6f;
+    out.margin = kFastSlabMargin * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-6f;
     for (int a = 0; a < 3; ++a) {
         out.bmin[a] = smn[a];
         out.bmax[a] = smx[a];

@@ -13,6 +13,13 @@ namespace rb {
 
 constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (LDS)
 constexpr uint32_t kDefaultStripeRows = 16;
+#ifndef RB_FAST_SLAB_MARGIN
+#define RB_FAST_SLAB_MARGIN 2e-5f
+#endif
+// fast triangle walk: part of the box inflation that covers the rounding of the slab tests themselves,
+// as a fraction of the mesh diagonal: their error is a few 2^-24 (~2.4e-7) of the coordinates involved, so
+// 2e-5 leaves two orders of magnitude; 1e-4 cost 9 % on a million small triangles
+constexpr float kFastSlabMargin = RB_FAST_SLAB_MARGIN;
 
 // ---- rb_bvh.cpp
 void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_node>& nodes,

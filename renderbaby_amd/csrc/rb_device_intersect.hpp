@@ -239,6 +239,9 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 // The walk is written as a resumable object so that the same steps serve the per-segment kernels
 // (intersect_bvh_fast below: run to completion) and the stepped kernel (k_trace_fast: lanes that
 // finish are shaded and refilled while the others keep walking).
+#ifndef RB_FAST_NODE_S
+#define RB_FAST_NODE_S 1
+#endif
 template <bool STATS>
 struct FastWalk {
     f3 o, d, inv;
@@ -259,8 +262,9 @@ struct FastWalk {
         best_rank = 0xFFFFFFFFu;
         inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
         // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
-        // triangle).  A child's box is inflated by m + 0.01 * S * (largest |e1||e2| below it): how far
-        // from its triangle a Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
+        // triangle); with RB_FAST_NODE_S the per-box bound of entry() is used instead.  A child's box is
+        // inflated by m + 0.01 * S * (largest |e1||e2| below it): how far from its triangle a
+        // Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
         const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
         const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
                     sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
@@ -296,9 +300,18 @@ struct FastWalk {
     }
 
     DEV bool entry(const KParams& p, v4f lo, v4f hi, float amax, float& tn) const {
+#if RB_FAST_NODE_S
+        // |s| = |origin - v0| of the triangles below this box is at most the distance to its farthest corner
+        const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
+        const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
+        const float mm = p.fast_margin + (0.01001f * __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz)) * amax;
+        const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
+        const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
+#else
         const float mm = p.fast_margin + S * amax;
         const f3 t0 = (mk(lo.x - mm, lo.y - mm, lo.z - mm) - o) * inv;
         const f3 t1 = (mk(hi.x + mm, hi.y + mm, hi.z + mm) - o) * inv;
+#endif
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);

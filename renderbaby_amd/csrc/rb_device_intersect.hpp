@@ -304,6 +304,7 @@ struct FastWalk {
         // |s| = |origin - v0| of the triangles below this box is at most the distance to its farthest corner
         const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
         const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
+        // (|x| + |y| + |z| instead of the root: no sqrt, but the looser bound costs 3-8 %)
         const float mm = p.fast_margin + (0.01001f * __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz)) * amax;
         const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
         const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;

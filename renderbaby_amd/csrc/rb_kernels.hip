@@ -172,6 +172,22 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
 // shader.wgsl:712-717), then tone-maps and packs (:720-722).  Phase 2 is a
 // coalesced 1 KiB-per-wave stream and is HBM-bound; phase 1 is ALU-bound.
 constexpr uint32_t kTraceBlock = 256;
+
+// One path's radiance -> its (pixel, sample) slot of the colour buffer, read once by k_accumulate.
+// Lanes finish at different times, so these are lone 16-byte stores: HBM takes them as 32-byte
+// writes (measured 2.2x the payload).  Streaming stores at least avoid the line fills and the early
+// partial write-backs of cached ones (2.45x plus 0.2x fetched); the kernel time is the same either way.
+#ifndef RB_COLOR_STORE_NT
+#define RB_COLOR_STORE_NT 1
+#endif
+DEV void store_color(float4* __restrict__ colors, uint32_t item, f3 c) {
+#if RB_COLOR_STORE_NT
+    const v4f v = {c.x, c.y, c.z, 0.0f};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(colors) + item);
+#else
+    colors[item] = make_float4(c.x, c.y, c.z, 0.0f);
+#endif
+}
 #ifndef RB_TRACE_WAVES
 #define RB_TRACE_WAVES 6
 #endif
@@ -264,7 +280,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
         if (active) {
             const bool alive = segment<STATS>(p, pt, &s_stack[tid], kTraceBlock, tl);
             if (!alive) {
-                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                store_color(colors, item, pt.color);
                 tl.paths++;
                 active = false;
             }
@@ -469,7 +485,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
             if (alive) {
                 state = BEGIN;
             } else {
-                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                store_color(colors, item, pt.color);
                 tl.paths++;
                 state = IDLE;
             }
@@ -617,7 +633,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
             if (alive) {
                 state = BEGIN;
             } else {
-                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                store_color(colors, item, pt.color);
                 tl.paths++;
                 state = IDLE;
             }
@@ -757,7 +773,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
             if (alive) {
                 state = BEGIN;
             } else {
-                colors[item] = make_float4(pt.color.x, pt.color.y, pt.color.z, 0.0f);
+                store_color(colors, item, pt.color);
                 tl.paths++;
                 state = IDLE;
             }

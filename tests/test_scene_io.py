@@ -426,3 +426,21 @@ def test_json_export_writes_relative_object_paths(tmp_path):   # scene_exporter.
     scene_io.export_scene(d, sibling)
     assert json.load(open(sibling))["objects"][0]["path"] == os.path.join("..", "assets", "obj", "cube.obj")
     assert len(scene_io.load_scene(sibling).bvh_triangles) == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel,builder", [(2, "device-ploc"), (1, "host-sah")], ids=["queue", "pixel"])
+def test_deep_device_tree_with_the_other_dispatch_shapes(kernel, builder):
+    # the lamp scene's device-built tree is deeper than the 32-entry LDS stack: the persistent queue
+    # kernel spills to the global scratch column, the one-thread-per-pixel kernel (unbounded grid)
+    # falls back to the depth-limited host builder; same frame either way
+    from renderbaby_amd import Engine, RenderConfig
+    s = _refscenes.ref_lamp(width=64, height=64, spp=2)
+    o_acc, _, o_rgba, _ = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, kernel=kernel, device_bvh=True)
+    f = e.render(rc)
+    acc = e.read_accumulation()
+    assert e.fast_bvh_builder()[0] == builder
+    e.close()
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)

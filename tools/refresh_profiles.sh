@@ -25,6 +25,11 @@ for w in c3 lamp; do
   tail -1 "$out/${w}_fast.json" > "profiles/${tag}_${w}_fastbvh_bench.json"
 done
 python bench.py --workload lamp --device-bvh --steps 3 --warmup 1 > "$out/lamp_dev.json" 2> "$out/lamp_dev.err"; tail -1 "$out/lamp_dev.json" > "profiles/${tag}_lamp_devicebvh_bench.json"
+for m in "" "--fast-bvh" "--device-bvh"; do
+  n=exact; [ "$m" = "--fast-bvh" ] && n=fast; [ "$m" = "--device-bvh" ] && n=dev
+  echo "[refresh] bench c5 geometry at 64 spp $m"; python bench.py --workload c5 --spp 64 $m --steps 2 --warmup 1 > "$out/c5_$n.json" 2> "$out/c5_$n.err"
+  tail -1 "$out/c5_$n.json" > "profiles/${tag}_c5_64spp_${n}_bench.json"
+done
 echo "[refresh] bench c2 (headline)"; python bench.py > "$out/c2.json" 2> "$out/c2.err"
 tail -1 "$out/c2.json" > "profiles/${tag}_c2_bench.json"
 mkdir -p "$R/gpurun_out/profiles_$tag" && cp profiles/${tag}_* profiles/traffic_${tag}_c2.json "$R/gpurun_out/profiles_$tag/"

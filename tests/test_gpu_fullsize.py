@@ -85,3 +85,22 @@ def test_c3_fast_bvh_equals_reference_walk_on_the_full_frame():
         diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
         assert out["exact"][1] == out[mode][1]
+
+
+def test_reference_lamp_scene_fast_walk_equals_reference_walk_at_full_size():
+    # the reference's own largest fixture scene at its real 2056 x 2056 frame (4 of its 512 spp,
+    # 68 M segments through 68 768 triangles, huge wall triangles next to sub-millimetre ones): the
+    # opt-in walk over the host- and the device-built tree must not change a single bit of the frame
+    from tests import _refscenes
+    s = _refscenes.ref_lamp(spp=4)
+    rc = RenderConfig.from_scene(s)
+    out = {}
+    for mode in ("exact", "host-sah", "device-ploc"):
+        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-ploc"))
+        e.render(rc)
+        out[mode] = (e.read_accumulation(), e.stats()["segments"])
+        e.close()
+    for mode in ("host-sah", "device-ploc"):
+        diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
+        assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
+        assert out["exact"][1] == out[mode][1]

@@ -510,6 +510,12 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #ifndef RB_FAST_NODE_LANES
 #define RB_FAST_NODE_LANES 16   // ... or fewer than this many are at inner nodes
 #endif
+#ifndef RB_FAST_NODE_STEPS
+#define RB_FAST_NODE_STEPS 2
+#endif
+#ifndef RB_SPH_NODE_STEPS
+#define RB_SPH_NODE_STEPS 2
+#endif
 #ifndef RB_FAST_WAVES
 #define RB_FAST_WAVES 4
 #endif
@@ -619,7 +625,13 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
                 if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, tl)) state = FINISH;
                 if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
             } else {
-                if (at_node && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
+                if (at_node) {
+                    if (!w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
+#if RB_FAST_NODE_STEPS > 1   // a lane reaches a leaf only every ~6 nodes: take more than one step per vote
+                    for (int extra = 1; extra < RB_FAST_NODE_STEPS; ++extra)
+                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
+#endif
+                }
             }
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
         }
@@ -759,7 +771,13 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
                 if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, n_tested)) state = FINISH;
                 if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
             } else {
-                if (at_node && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
+                if (at_node) {
+                    if (!w.node_step(p, stack, kTraceBlock)) state = FINISH;
+#if RB_SPH_NODE_STEPS > 1
+                    for (int extra = 1; extra < RB_SPH_NODE_STEPS; ++extra)
+                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
+#endif
+                }
             }
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
         }

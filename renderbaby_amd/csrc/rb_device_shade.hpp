@@ -490,10 +490,11 @@ DEV Cam make_cam(const KParams& p) {
     c.hm1 = (float)(p.u.height - 1u);
     return c;
 }
-// shader.wgsl:693-709
-DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
-                    uint32_t sample_offset, Path& pt) {
-    uint32_t seed = pcg(pixel_index + pcg(sample_offset));
+// shader.wgsl:693-709; `sample_hash` = hash(current_pass * samples_per_pass + sample), the part of the seed
+// that does not depend on the pixel
+DEV void start_path_hashed(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
+                           uint32_t sample_hash, Path& pt) {
+    uint32_t seed = pcg(pixel_index + sample_hash);
     const float off_x = rnd(seed) - 0.5f;
     const float off_y = rnd(seed) - 0.5f;
     const float u = ((((float)x + off_x) / c.wm1) * 2.0f - 1.0f) * c.aspect;
@@ -506,9 +507,15 @@ DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint
     pt.depth = 0;
 }
 
+DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
+                    uint32_t sample_offset, Path& pt) {
+    start_path_hashed(p, c, x, y, pixel_index, pcg(sample_offset), pt);
+}
+
 // global image row of local row `ly` (interleaved stripes)
 DEV uint32_t global_row(const KParams& p, uint32_t ly) {
     if (p.shard_count <= 1u) return ly;
+    if (p.stripe_rows == 1u) return ly * p.shard_count + p.shard_rank;  // no division for one-row stripes
     const uint32_t s = ly / p.stripe_rows, r = ly % p.stripe_rows;
     return (s * p.shard_count + p.shard_rank) * p.stripe_rows + r;
 }
@@ -521,6 +528,61 @@ DEV void store_pixel(const KParams& p, uint32_t x, uint32_t ly, f3 acc, uint32_t
     const f3 fin = divs(acc, ts);
     const f3 mapped = mk(fin.x / (fin.x + 1.0f), fin.y / (fin.y + 1.0f), fin.z / (fin.z + 1.0f));
     p.out_rgba[(size_t)ly * p.u.width + (p.u.width - 1u - x)] = color_map(mapped);
+}
+
+// ---- (pixel, sample) items of the stream kernels.  Item = (tile * S + sample) * 64 + pixel-in-tile.
+// A refill round hands out at most 64 consecutive items starting at the wave-uniform `base`, so a
+// lane's item lies in the 64-item row of `base` or in the next one: tile, sample and the sample's
+// hash are worked out once per round for those two rows with scalar arithmetic (division by the
+// launch constants via host-made reciprocals), and a lane only selects between them.
+DEV uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t& rem) {
+    uint32_t q = __umulhi(n, magic);  // magic = floor(2^32 / d) (0xFFFFFFFF for d = 1): q is exact or one low
+    uint32_t r = n - q * d;
+    if (r >= d) {
+        q++;
+        r -= d;
+    }
+    rem = r;
+    return q;
+}
+struct ItemRows {
+    uint32_t in0;
+    uint32_t tx[2], ty[2], hs[2];
+};
+DEV ItemRows item_rows(const KParams& p, uint32_t base, uint32_t S, uint32_t tiles_x, uint32_t sample_base) {
+    ItemRows r;
+    r.in0 = base & 63u;
+    uint32_t smp, tx;
+    const uint32_t tile = udiv_magic(base >> 6, S, p.magic_S, smp);
+    const uint32_t ty = udiv_magic(tile, tiles_x, p.magic_tiles_x, tx);
+    r.tx[0] = tx;
+    r.ty[0] = ty;
+    r.hs[0] = pcg(sample_base + smp);
+    uint32_t smp1 = smp + 1u, tx1 = tx, ty1 = ty;
+    if (smp1 == S) {
+        smp1 = 0u;
+        tx1++;
+        if (tx1 == tiles_x) {
+            tx1 = 0u;
+            ty1++;
+        }
+    }
+    r.tx[1] = tx1;
+    r.ty[1] = ty1;
+    r.hs[1] = pcg(sample_base + smp1);
+    return r;
+}
+// this lane's pixel for the item `base + rank`; false for the padding pixels of edge tiles and stripes
+DEV bool item_pixel(const KParams& p, const ItemRows& r, uint32_t rank, uint32_t& x, uint32_t& y, uint32_t& sample_hash) {
+    const uint32_t idx = r.in0 + rank, in = idx & 63u;
+    const bool next = idx >= 64u;
+    const uint32_t tx = next ? r.tx[1] : r.tx[0], ty = next ? r.ty[1] : r.ty[0];
+    sample_hash = next ? r.hs[1] : r.hs[0];
+    x = tx * 8u + (in & 7u);
+    const uint32_t ly = ty * 8u + (in >> 3);
+    if (!((x < p.u.width) && (ly < p.local_rows))) return false;
+    y = global_row(p, ly);
+    return y < p.u.height;
 }
 
 }  // namespace

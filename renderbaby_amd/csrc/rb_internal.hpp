@@ -148,6 +148,7 @@ struct KParams {
     uint32_t queue_batch;          // items a wave reserves per global atomic (RB_KERNEL_STREAM)
     uint32_t no_leaf_stepping;     // RB_KERNEL_STREAM: 1 = per-segment traversal even for multi-node trees
     uint32_t lds_mode;             // LDS staging of small meshes: 0 = when it fits, 1 = never
+    uint32_t magic_S, magic_tiles_x; // floor(2^32 / d) for the item decode of the stream kernels (set by launch_render)
     uint32_t* stack_overflow;      // fast walk: entries beyond kStackDepth, [entry][grid * block] (nullptr if never needed)
 };
 

@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
+            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = !active && rank < avail;
@@ -239,24 +240,15 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
             const uint32_t taken = n_idle < avail ? n_idle : avail;
             if (take) {
                 const uint32_t it = loc_next + rank;
-                const uint32_t in = it & 63u, ts = it >> 6;
-                const uint32_t tile = ts / S, smp = ts - tile * S;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
-                bool ok = (x < width) && (ly < p.local_rows);
-                uint32_t y = 0;
-                if (ok) {
-                    y = global_row(p, ly);
-                    ok = y < p.u.height;
-                }
-                if (ok) {
-                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                uint32_t x = 0, y = 0, sample_hash = 0;
+                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
+                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
 #if RB_ABLATE == 4
                     {
                         Path p2;
                         uint32_t x2 = x;
                         asm volatile("" : "+v"(x2));
-                        start_path(p, cam, x2, y, y * width + x2, sample_base + smp, p2);
+                        start_path_hashed(p, cam, x2, y, y * width + x2, sample_hash, p2);
                         asm volatile("" ::"v"(p2.d.x), "v"(p2.d.y), "v"(p2.d.z), "v"(p2.seed));
                     }
 #endif
@@ -376,6 +368,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
+            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = (state == IDLE) && rank < avail;
@@ -383,18 +376,9 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
             const uint32_t taken = n_idle < avail ? n_idle : avail;
             if (take) {
                 const uint32_t it = loc_next + rank;
-                const uint32_t in = it & 63u, ts = it >> 6;
-                const uint32_t tile = ts / S, smp = ts - tile * S;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
-                bool ok = (x < width) && (ly < p.local_rows);
-                uint32_t y = 0;
-                if (ok) {
-                    y = global_row(p, ly);
-                    ok = y < p.u.height;
-                }
-                if (ok) {
-                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                uint32_t x = 0, y = 0, sample_hash = 0;
+                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
+                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
                     item = it;
                     if (p.u.max_depth > 0u) {
                         state = BEGIN;
@@ -564,6 +548,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
+            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = (state == IDLE) && rank < avail;
@@ -571,18 +556,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
             const uint32_t taken = n_idle < avail ? n_idle : avail;
             if (take) {
                 const uint32_t it = loc_next + rank;
-                const uint32_t in = it & 63u, ts = it >> 6;
-                const uint32_t tile = ts / S, smp = ts - tile * S;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
-                bool ok = (x < width) && (ly < p.local_rows);
-                uint32_t y = 0;
-                if (ok) {
-                    y = global_row(p, ly);
-                    ok = y < p.u.height;
-                }
-                if (ok) {
-                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                uint32_t x = 0, y = 0, sample_hash = 0;
+                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
+                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
                     item = it;
                     if (p.u.max_depth > 0u) {
                         state = BEGIN;
@@ -712,6 +688,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
+            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = (state == IDLE) && rank < avail;
@@ -719,18 +696,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
             const uint32_t taken = n_idle < avail ? n_idle : avail;
             if (take) {
                 const uint32_t it = loc_next + rank;
-                const uint32_t in = it & 63u, ts = it >> 6;
-                const uint32_t tile = ts / S, smp = ts - tile * S;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                const uint32_t x = tx * 8u + (in & 7u), ly = ty * 8u + (in >> 3);
-                bool ok = (x < width) && (ly < p.local_rows);
-                uint32_t y = 0;
-                if (ok) {
-                    y = global_row(p, ly);
-                    ok = y < p.u.height;
-                }
-                if (ok) {
-                    start_path(p, cam, x, y, y * width + x, sample_base + smp, pt);
+                uint32_t x = 0, y = 0, sample_hash = 0;
+                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
+                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
                     item = it;
                     if (p.u.max_depth > 0u) {
                         state = BEGIN;
@@ -1035,6 +1003,11 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         if (batch > 4096u) batch = 4096u;
         if (p.queue_batch) batch = p.queue_batch;
         q.queue_batch = (uint32_t)batch;
+        {   // reciprocals for the item -> (tile, sample) -> (tx, ty) divisions (udiv_magic)
+            const uint64_t S = (uint64_t)p.n_passes * p.samples_per_pass, tiles_x = (p.u.width + 7u) / 8u;
+            q.magic_S = S > 1u ? (uint32_t)((1ull << 32) / S) : 0xFFFFFFFFu;
+            q.magic_tiles_x = tiles_x > 1u ? (uint32_t)((1ull << 32) / tiles_x) : 0xFFFFFFFFu;
+        }
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
         const bool sph_stepped = !fast_stepped && !stepped && p.sph_nodes != nullptr && !p.no_leaf_stepping;

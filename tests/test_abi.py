@@ -67,3 +67,22 @@ def test_create_rejects_non_create_fields_without_touching_the_gpu():
     assert not lib.rb_create(C.byref(cfg))
     assert b"Invalid Spheres" in lib.rb_last_error(None)
     assert not lib.rb_create(None)
+
+
+def test_entry_points_reject_a_null_engine_without_touching_the_gpu():
+    # every entry point that takes an engine must come back with RB_ERR_NULL_ARGUMENT (or a neutral
+    # value) for NULL instead of crashing -- the reference's callers would see a panic there
+    lib = _lib.load()
+    buf = (C.c_uint8 * 16)()
+    w, h, ms = C.c_uint32(), C.c_uint32(), C.c_float(5.0)
+    null = None
+    assert lib.rb_update(null, None) != 0 and lib.rb_render(null, buf) != 0
+    assert lib.rb_iter_begin(null, None) != 0 and lib.rb_iter_has_next(null) == 0 and lib.rb_iter_next(null, buf) != 0
+    assert lib.rb_iter_set_passes_per_frame(null, 4) != 0
+    assert lib.rb_get_size(null, C.byref(w), C.byref(h)) != 0
+    assert lib.rb_clear(null) != 0 and lib.rb_dispatch(null, 0, 1) != 0 and lib.rb_sync(null) != 0
+    assert lib.rb_read_rgba(null, buf) != 0 and lib.rb_read_accumulation(null, buf) != 0
+    assert (lib.rb_fast_bvh_builder(null, C.byref(ms)) or b"") == b"" and ms.value == 0.0
+    assert (lib.rb_last_kernel_name(null) or b"") == b""
+    lib.rb_iter_destroy(null)
+    lib.rb_destroy(null)

@@ -983,16 +983,23 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
     } else {
         const uint64_t tiles = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u);
         const uint64_t items = tiles * 64u * p.n_passes * p.samples_per_pass;
-        const bool stepped = p.u.bvh_node_count > 1u && !p.no_leaf_stepping && p.fast_nodes == nullptr;
-        // small meshes: stage the tree and the triangles' first 48 B in LDS next to the stacks, one
-        // 1024-thread block per CU (measured faster than three 256-thread blocks with their own copies)
+        // which trace kernel: multi-node tree walked exactly (from LDS when the mesh fits next to the
+        // stacks: one 1024-thread block per CU, measured faster than three 256-thread blocks with a copy
+        // each), the opt-in walk, the sphere tree, or the plain kernel (single-node tree, <= 64 spheres)
+        enum Variant { PLAIN, BVH, BVH_LDS, FAST, SPH };
+        const bool multi = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
         const size_t scene_lds = (size_t)p.u.bvh_node_count * 48u + (size_t)p.index_len * 48u;
-        const bool lds_big = stepped && p.lds_mode != 1u && lds * 4u + scene_lds <= 160u * 1024u;
-        li.block = lds_big ? 1024u : kTraceBlock;
-        const bool fast_stepped = p.fast_nodes != nullptr && p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
-        const bool sph_stepped_grid = !fast_stepped && !stepped && p.sph_nodes != nullptr && !p.no_leaf_stepping;
-        // residency: k_trace 6 waves/SIMD, k_trace_fast 4 (registers)
-        li.grid = persistent_blocks(items, li.block, lds_big ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (fast_stepped || sph_stepped_grid) ? 4u : 8u);
+        Variant v = PLAIN;
+        if (multi && p.fast_nodes != nullptr) v = FAST;
+        else if (multi) v = (p.lds_mode != 1u && lds * 4u + scene_lds <= 160u * 1024u) ? BVH_LDS : BVH;
+        else if (p.sph_nodes != nullptr && !p.no_leaf_stepping) v = SPH;
+        static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph"};
+        li.kernel_name = names[v];
+        li.block = v == BVH_LDS ? 1024u : kTraceBlock;
+        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : lds;
+        // residency (registers): k_trace 6 waves/SIMD, the stepped walks 4
+        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : 8u;
+        li.grid = persistent_blocks(items, li.block, blocks_per_cu);
         if (li.grid == 0) return 0;
         // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64
         KParams q = p;
@@ -1010,38 +1017,32 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         }
         hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
-        const bool sph_stepped = !fast_stepped && !stepped && p.sph_nodes != nullptr && !p.no_leaf_stepping;
-        li.kernel_name = sph_stepped ? "k_trace_sph" : fast_stepped ? "k_trace_fast" : stepped ? (lds_big ? "k_trace_bvh_lds" : "k_trace_bvh") : "k_trace";
-        if (sph_stepped) {
-            if (stats)
-                hipLaunchKernelGGL(k_trace_sph<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
-            else
-                hipLaunchKernelGGL(k_trace_sph<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
-        } else if (fast_stepped) {
-            if (stats)
-                hipLaunchKernelGGL(k_trace_fast<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
-            else
-                hipLaunchKernelGGL(k_trace_fast<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
-        } else
-        if (lds_big) {
-            li.lds_bytes = lds * 4u + scene_lds;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<true, true, 1024u>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<false, true, 1024u>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
-            if (stats)
-                hipLaunchKernelGGL((k_trace_bvh<true, true, 1024u>), dim3(li.grid), dim3(1024), li.lds_bytes, stream, q);
-            else
-                hipLaunchKernelGGL((k_trace_bvh<false, true, 1024u>), dim3(li.grid), dim3(1024), li.lds_bytes, stream, q);
-        } else if (stepped) {
-            if (stats)
-                hipLaunchKernelGGL((k_trace_bvh<true, false, kTraceBlock>), dim3(li.grid), dim3(li.block), lds, stream, q);
-            else
-                hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), dim3(li.grid), dim3(li.block), lds, stream, q);
-        } else if (stats) {
-            hipLaunchKernelGGL(k_trace<true>, dim3(li.grid), dim3(li.block), lds, stream, q);
-        } else {
-            hipLaunchKernelGGL(k_trace<false>, dim3(li.grid), dim3(li.block), lds, stream, q);
+        const dim3 grid(li.grid), block(li.block);
+        switch (v) {
+            case SPH:
+                if (stats) hipLaunchKernelGGL(k_trace_sph<true>, grid, block, lds, stream, q);
+                else hipLaunchKernelGGL(k_trace_sph<false>, grid, block, lds, stream, q);
+                break;
+            case FAST:
+                if (stats) hipLaunchKernelGGL(k_trace_fast<true>, grid, block, lds, stream, q);
+                else hipLaunchKernelGGL(k_trace_fast<false>, grid, block, lds, stream, q);
+                break;
+            case BVH_LDS:
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<true, true, 1024u>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<false, true, 1024u>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
+                if (stats) hipLaunchKernelGGL((k_trace_bvh<true, true, 1024u>), grid, block, li.lds_bytes, stream, q);
+                else hipLaunchKernelGGL((k_trace_bvh<false, true, 1024u>), grid, block, li.lds_bytes, stream, q);
+                break;
+            case BVH:
+                if (stats) hipLaunchKernelGGL((k_trace_bvh<true, false, kTraceBlock>), grid, block, lds, stream, q);
+                else hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), grid, block, lds, stream, q);
+                break;
+            case PLAIN:
+                if (stats) hipLaunchKernelGGL(k_trace<true>, grid, block, lds, stream, q);
+                else hipLaunchKernelGGL(k_trace<false>, grid, block, lds, stream, q);
+                break;
         }
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

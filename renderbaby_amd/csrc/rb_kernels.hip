@@ -192,6 +192,53 @@ DEV void store_color(float4* __restrict__ colors, uint32_t item, f3 c) {
 #define RB_TRACE_WAVES 6
 #endif
 
+// The (pixel, sample) work queue of the stream kernels, one instance per wavefront.  The global
+// queue word is touched once per `batch` items (one word sustains only ~90 M atomics/s chip-wide);
+// inside a batch the wave hands items to its idle lanes with ballot + prefix count, no memory
+// traffic.  `is_idle()` is the calling kernel's notion of an idle lane, `on_item(item, x, y,
+// sample_hash)` starts a path on the calling lane (padding pixels of edge tiles are skipped here).
+struct ItemQueue {
+    uint32_t loc_next = 0, loc_end = 0;  // this wave's reserved item range (wave-uniform)
+    uint32_t batch;                      // items per reservation
+    bool exhausted = false;
+    DEV explicit ItemQueue(uint32_t batch_) : batch(batch_) {}
+
+    DEV bool drained() const { return exhausted && loc_next == loc_end; }
+
+    template <class IsIdle, class OnItem>
+    DEV void refill(const KParams& p, uint32_t lane, uint32_t total_items, uint32_t S, uint32_t tiles_x,
+                    uint32_t sample_base, IsIdle&& is_idle, OnItem&& on_item) {
+        unsigned long long idle = __ballot(is_idle());
+        for (int round = 0; round < 2 && idle != 0ull; round++) {
+            if (loc_next == loc_end) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(p.queue, batch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= total_items) {
+                    exhausted = true;
+                    break;
+                }
+                loc_next = b;
+                loc_end = (total_items - b < batch) ? total_items : b + batch;
+            }
+            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
+            const uint32_t avail = loc_end - loc_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = ((idle >> lane) & 1ull) != 0ull && rank < avail;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t taken = n_idle < avail ? n_idle : avail;
+            if (take) {
+                uint32_t x = 0, y = 0, sample_hash = 0;
+                if (item_pixel(p, rows, rank, x, y, sample_hash)) on_item(loc_next + rank, x, y, sample_hash);
+            }
+            loc_next += taken;
+            idle = __ballot(is_idle());
+            if (taken == n_idle) break;  // everyone who asked was served (or got a padding item)
+        }
+    }
+};
+
 template <bool STATS>
 __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
@@ -215,9 +262,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
     pt.depth = 0;
 
     for (;;) {
-        // ---- hand items to idle lanes.  The global queue is touched once per `batch`
-        // items (one word sustains only ~90 M atomics/s chip-wide); inside a batch the
-        // wave allocates with ballot + prefix count, no memory traffic.
+        // ---- hand items to idle lanes: ItemQueue::refill spelled out (in this kernel, the hottest one,
+        // the helper form changes the register allocation and costs 0.8 %)
         unsigned long long idle = __ballot(!active);
         for (int round = 0; round < 2 && idle != 0ull; round++) {
             if (loc_next == loc_end) {
@@ -339,9 +385,8 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
-    bool exhausted = false;
-    uint32_t item = 0, loc_next = 0, loc_end = 0;
-    const uint32_t batch = p.queue_batch;
+    uint32_t item = 0;
+    ItemQueue iq(p.queue_batch);
     Path pt;
     pt.depth = 0;
     TriHit th;
@@ -353,47 +398,20 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     int sp = 0;
 
     for (;;) {
-        // ---- (1) hand items to idle lanes (same scheme as k_trace)
-        unsigned long long idle = __ballot(state == IDLE);
-        for (int round = 0; round < 2 && idle != 0ull; round++) {
-            if (loc_next == loc_end) {
-                if (exhausted) break;
-                uint32_t b = 0;
-                if (lane == 0u) b = atomicAdd(p.queue, batch);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= total_items) {
-                    exhausted = true;
-                    break;
-                }
-                loc_next = b;
-                loc_end = (total_items - b < batch) ? total_items : b + batch;
-            }
-            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
-            const uint32_t avail = loc_end - loc_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const bool take = (state == IDLE) && rank < avail;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const uint32_t taken = n_idle < avail ? n_idle : avail;
-            if (take) {
-                const uint32_t it = loc_next + rank;
-                uint32_t x = 0, y = 0, sample_hash = 0;
-                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
-                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
-                    item = it;
-                    if (p.u.max_depth > 0u) {
-                        state = BEGIN;
-                    } else {
-                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        tl.paths++;
-                    }
-                }
-            }
-            loc_next += taken;
-            idle = __ballot(state == IDLE);
-            if (taken == n_idle) break;
-        }
+        // ---- (1) hand items to idle lanes
+        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
+                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                      item = it;
+                      if (p.u.max_depth > 0u) {
+                          state = BEGIN;
+                      } else {
+                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                          tl.paths++;
+                      }
+                  });
         if (__ballot(state != IDLE) == 0ull) {
-            if (exhausted && loc_next == loc_end) break;
+            if (iq.drained()) break;
             continue;
         }
 
@@ -521,9 +539,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
-    bool exhausted = false;
-    uint32_t item = 0, loc_next = 0, loc_end = 0;
-    const uint32_t batch = p.queue_batch;
+    uint32_t item = 0;
+    ItemQueue iq(p.queue_batch);
     Path pt;
     pt.depth = 0;
     FastWalk<STATS> w;
@@ -533,47 +550,20 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 #endif
 
     for (;;) {
-        // ---- (1) hand items to idle lanes (same scheme as k_trace)
-        unsigned long long idle = __ballot(state == IDLE);
-        for (int round = 0; round < 2 && idle != 0ull; round++) {
-            if (loc_next == loc_end) {
-                if (exhausted) break;
-                uint32_t b = 0;
-                if (lane == 0u) b = atomicAdd(p.queue, batch);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= total_items) {
-                    exhausted = true;
-                    break;
-                }
-                loc_next = b;
-                loc_end = (total_items - b < batch) ? total_items : b + batch;
-            }
-            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
-            const uint32_t avail = loc_end - loc_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const bool take = (state == IDLE) && rank < avail;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const uint32_t taken = n_idle < avail ? n_idle : avail;
-            if (take) {
-                const uint32_t it = loc_next + rank;
-                uint32_t x = 0, y = 0, sample_hash = 0;
-                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
-                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
-                    item = it;
-                    if (p.u.max_depth > 0u) {
-                        state = BEGIN;
-                    } else {
-                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        tl.paths++;
-                    }
-                }
-            }
-            loc_next += taken;
-            idle = __ballot(state == IDLE);
-            if (taken == n_idle) break;
-        }
+        // ---- (1) hand items to idle lanes
+        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
+                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                      item = it;
+                      if (p.u.max_depth > 0u) {
+                          state = BEGIN;
+                      } else {
+                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                          tl.paths++;
+                      }
+                  });
         if (__ballot(state != IDLE) == 0ull) {
-            if (exhausted && loc_next == loc_end) break;
+            if (iq.drained()) break;
             continue;
         }
 
@@ -655,9 +645,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
-    bool exhausted = false;
-    uint32_t item = 0, loc_next = 0, loc_end = 0;
-    const uint32_t batch = p.queue_batch;
+    uint32_t item = 0;
+    ItemQueue iq(p.queue_batch);
     Path pt;
     pt.depth = 0;
     SphereWalk w;
@@ -673,47 +662,20 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const 
     if constexpr (STATS) n_tested = &tl.spheres;
 
     for (;;) {
-        // ---- (1) hand items to idle lanes (same scheme as k_trace)
-        unsigned long long idle = __ballot(state == IDLE);
-        for (int round = 0; round < 2 && idle != 0ull; round++) {
-            if (loc_next == loc_end) {
-                if (exhausted) break;
-                uint32_t b = 0;
-                if (lane == 0u) b = atomicAdd(p.queue, batch);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= total_items) {
-                    exhausted = true;
-                    break;
-                }
-                loc_next = b;
-                loc_end = (total_items - b < batch) ? total_items : b + batch;
-            }
-            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
-            const uint32_t avail = loc_end - loc_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const bool take = (state == IDLE) && rank < avail;
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const uint32_t taken = n_idle < avail ? n_idle : avail;
-            if (take) {
-                const uint32_t it = loc_next + rank;
-                uint32_t x = 0, y = 0, sample_hash = 0;
-                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
-                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
-                    item = it;
-                    if (p.u.max_depth > 0u) {
-                        state = BEGIN;
-                    } else {
-                        colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        tl.paths++;
-                    }
-                }
-            }
-            loc_next += taken;
-            idle = __ballot(state == IDLE);
-            if (taken == n_idle) break;
-        }
+        // ---- (1) hand items to idle lanes
+        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
+                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                      item = it;
+                      if (p.u.max_depth > 0u) {
+                          state = BEGIN;
+                      } else {
+                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                          tl.paths++;
+                      }
+                  });
         if (__ballot(state != IDLE) == 0ull) {
-            if (exhausted && loc_next == loc_end) break;
+            if (iq.drained()) break;
             continue;
         }
 

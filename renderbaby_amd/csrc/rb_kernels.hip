@@ -521,8 +521,63 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #ifndef RB_FAST_WAVES
 #define RB_FAST_WAVES 4
 #endif
+// What trace_stepped needs from a resumable walk: the opt-in triangle walk ...
 template <bool STATS>
-__global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const KParams p) {
+struct TriangleWalkPolicy {
+    static constexpr int kNodeSteps = RB_FAST_NODE_STEPS;
+    FastWalk<STATS> w;
+    DEV void init(const KParams& p) { w.begin(p, mk(0, 0, 0), mk(0, 0, 1)); }
+    DEV void begin(const KParams& p, const Path& pt, uint32_t*, Tally<STATS>&) { w.begin(p, pt.o, pt.d); }
+    DEV bool at_leaf() const { return w.at_leaf(); }
+    DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.node_step(p, stack, kTraceBlock, tl); }
+    DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.leaf_step(p, stack, kTraceBlock, tl); }
+    DEV bool finish(const KParams& p, Path& pt, uint32_t* stack, Tally<STATS>& tl) {
+        return segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
+    }
+};
+// ... and the sphere tree (scenes with more than 64 spheres, BASELINE C4; in the per-segment form a
+// wavefront walked it with 16 % of its lanes busy), between segment_pre (ground, the at most
+// single-node triangle list) and segment_post (lights, shading).  Used when there is no multi-node
+// triangle tree to walk as well.
+template <bool STATS>
+struct SphereWalkPolicy {
+    static constexpr int kNodeSteps = RB_SPH_NODE_STEPS;
+    SphereWalk w;
+    TriHit th;
+    SegState st;
+    DEV void init(const KParams& p) {
+        w.begin(p, mk(0, 0, 0), mk(0, 0, 1), 1.0f, 1e20f);
+        th.hit = false;
+        th.t = 1e20f;
+        th.u = th.v = 0.0f;
+        th.slot = 0u;
+        st.closest_t = 1e20f;
+        st.kind = K_NONE;
+        st.uvx = st.uvy = 0.0f;
+        st.use_tex = st.tri_won_a = false;
+    }
+    DEV void begin(const KParams& p, const Path& pt, uint32_t* stack, Tally<STATS>& tl) {
+        th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, kTraceBlock, tl);
+        st = segment_pre<STATS>(p, pt, th, tl);
+        w.begin(p, pt.o, pt.d, dot(pt.d, pt.d), st.closest_t);
+    }
+    DEV bool at_leaf() const { return w.at_leaf(); }
+    DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>&) { return w.node_step(p, stack, kTraceBlock); }
+    DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) {
+        unsigned long long* n_tested = nullptr;
+        if constexpr (STATS) n_tested = &tl.spheres;
+        return w.leaf_step(p, stack, kTraceBlock, n_tested);
+    }
+    DEV bool finish(const KParams& p, Path& pt, uint32_t*, Tally<STATS>& tl) {
+        float closest_t = st.closest_t;
+        uint32_t sphere_idx = 0xFFFFFFFFu;
+        w.result(closest_t, sphere_idx);
+        return segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
+    }
+};
+
+template <bool STATS, class Walk>
+DEV void trace_stepped(const KParams& p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -543,8 +598,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
     ItemQueue iq(p.queue_batch);
     Path pt;
     pt.depth = 0;
-    FastWalk<STATS> w;
-    w.begin(p, mk(0, 0, 0), mk(0, 0, 1));
+    Walk w;
+    w.init(p);
 #ifdef RB_FAST_PROFILE  // -DRB_FAST_PROFILE: pass occupancy instead of the work counters (tools/ab.sh, RB_PRINT=1)
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -569,7 +624,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 
         // ---- (2) start of a segment
         if (state == BEGIN) {
-            w.begin(p, pt.o, pt.d);
+            w.begin(p, pt, stack, tl);
             state = TRAV;
         }
 
@@ -588,15 +643,14 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
             } else { prof[0]++; prof[1] += n_node; }
 #endif
             if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
-                if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, tl)) state = FINISH;
-                if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
+                if (at_leaf && !w.leaf_step(p, stack, tl)) state = FINISH;
+                if (n_leaf == 0u && at_node && !w.node_step(p, stack, tl)) state = FINISH;
             } else {
                 if (at_node) {
-                    if (!w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
-#if RB_FAST_NODE_STEPS > 1   // a lane reaches a leaf only every ~6 nodes: take more than one step per vote
-                    for (int extra = 1; extra < RB_FAST_NODE_STEPS; ++extra)
-                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, kTraceBlock, tl)) state = FINISH;
-#endif
+                    if (!w.node_step(p, stack, tl)) state = FINISH;
+                    // a lane reaches a leaf only every ~6 nodes: take more than one step per vote
+                    for (int extra = 1; extra < Walk::kNodeSteps; ++extra)
+                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, tl)) state = FINISH;
                 }
             }
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
@@ -605,9 +659,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 #ifdef RB_FAST_PROFILE
         { const uint32_t nf = (uint32_t)__popcll(__ballot(state == FINISH)); if (nf) { prof[4]++; prof[5] += nf; } }
 #endif
-        // ---- (4) finished walks: ground, spheres, lights, shading, next ray
+        // ---- (4) finished walks: the rest of the segment (shading), next ray
         if (state == FINISH) {
-            const bool alive = segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
+            const bool alive = w.finish(p, pt, stack, tl);
             if (alive) {
                 state = BEGIN;
             } else {
@@ -624,110 +678,13 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 #endif
 }
 
-// The sphere tree (scenes with more than 64 spheres, BASELINE C4) stepped the same way: in the
-// per-segment form a wavefront walked it with 16 % of its lanes busy.  Used when there is no
-// multi-node triangle tree to walk as well.
+template <bool STATS>
+__global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const KParams p) {
+    trace_stepped<STATS, TriangleWalkPolicy<STATS>>(p);
+}
 template <bool STATS>
 __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t width = p.u.width;
-    const uint32_t tiles_x = (width + 7u) / 8u;
-    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
-    const uint32_t S = p.n_passes * p.samples_per_pass;
-    const uint32_t total_items = tiles_x * tiles_y * S * 64u;
-    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
-    const Cam cam = make_cam(p);
-    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
-    uint32_t* const stack = &s_stack[tid];
-    Tally<STATS> tl;
-
-    enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
-    uint32_t state = IDLE;
-    uint32_t item = 0;
-    ItemQueue iq(p.queue_batch);
-    Path pt;
-    pt.depth = 0;
-    SphereWalk w;
-    w.begin(p, mk(0, 0, 0), mk(0, 0, 1), 1.0f, 1e20f);
-    TriHit th;
-    th.hit = false;
-    th.t = 1e20f;
-    th.u = th.v = 0.0f;
-    th.slot = 0u;
-    SegState st = segment_pre<STATS>(p, pt, th, tl);
-    tl.segments = 0;
-    unsigned long long* n_tested = nullptr;
-    if constexpr (STATS) n_tested = &tl.spheres;
-
-    for (;;) {
-        // ---- (1) hand items to idle lanes
-        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
-                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
-                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
-                      item = it;
-                      if (p.u.max_depth > 0u) {
-                          state = BEGIN;
-                      } else {
-                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                          tl.paths++;
-                      }
-                  });
-        if (__ballot(state != IDLE) == 0ull) {
-            if (iq.drained()) break;
-            continue;
-        }
-
-        // ---- (2) start of a segment: the (at most single-node) triangle list, ground, then the
-        // sphere walk starts from what they left as the closest hit
-        if (state == BEGIN) {
-            th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, kTraceBlock, tl);
-            st = segment_pre<STATS>(p, pt, th, tl);
-            w.begin(p, pt.o, pt.d, dot(pt.d, pt.d), st.closest_t);
-            state = TRAV;
-        }
-
-        // ---- (3) walk.  Every pass is either a node step for all lanes at an inner node or a leaf
-        // step for all lanes at a leaf -- whichever has enough lanes to be worth issuing (a lane
-        // reaches a leaf only every ~6 nodes, so waiting for ALL lanes to reach one would leave the
-        // node loop 20 % occupied).  At least one pass per outer iteration, then on while enough lanes
-        // are still walking.
-        for (;;) {
-            const bool at_node = state == TRAV && !w.at_leaf();
-            const bool at_leaf = state == TRAV && w.at_leaf();
-            const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-            if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
-                if (at_leaf && !w.leaf_step(p, stack, kTraceBlock, n_tested)) state = FINISH;
-                if (n_leaf == 0u && at_node && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
-            } else {
-                if (at_node) {
-                    if (!w.node_step(p, stack, kTraceBlock)) state = FINISH;
-#if RB_SPH_NODE_STEPS > 1
-                    for (int extra = 1; extra < RB_SPH_NODE_STEPS; ++extra)
-                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, kTraceBlock)) state = FINISH;
-#endif
-                }
-            }
-            if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
-        }
-
-        // ---- (4) finished walks: lights, shading, next ray
-        if (state == FINISH) {
-            float closest_t = st.closest_t;
-            uint32_t sphere_idx = 0xFFFFFFFFu;
-            w.result(closest_t, sphere_idx);
-            const bool alive = segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
-            if (alive) {
-                state = BEGIN;
-            } else {
-                store_color(colors, item, pt.color);
-                tl.paths++;
-                state = IDLE;
-            }
-        }
-    }
-    flush_tally<STATS>(tl, p.counters);
+    trace_stepped<STATS, SphereWalkPolicy<STATS>>(p);
 }
 
 // Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,

@@ -314,7 +314,12 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ co
         const float dx = fmaxf(a1.x, b1.x) - fminf(a0.x, b0.x), dy = fmaxf(a1.y, b1.y) - fminf(a0.y, b0.y),
                     dz = fmaxf(a1.z, b1.z) - fminf(a0.z, b0.z);
         const float area = dx * dy + dy * dz + dz * dx;
-        if (area < best) {  // ties: the lower position
+        // ties (coincident or equal boxes): the nearer position, and at equal distance the even
+        // positions look right and the odd ones left, so that a run of identical clusters still
+        // pairs up (0,1) (2,3) ... in one round instead of merging one pair per round
+        const uint32_t dist = j > i ? j - i : i - j, bdist = bj > i ? bj - i : i - bj;
+        const bool prefer = dist < bdist || (dist == bdist && ((i & 1u) ? j < i : j > i));
+        if (area < best || (area == best && prefer)) {
             best = area;
             bj = j;
         }
@@ -496,6 +501,12 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
                 if (e == hipSuccess) e = hipStreamSynchronize(stream);
                 if (e != hipSuccess) return done(e);
             }
+        }
+        if (live > 1u) {  // not reached in practice (every round merges at least the closest pair)
+            e = hipMemcpyAsync(&live, counters, 4, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return done(e);
+            if (live > 1u) return done(hipErrorNotReady);  // the caller falls back to the host builder
         }
         hipLaunchKernelGGL(k_ploc_finish, dim3(1), dim3(1), 0, stream, A, bounds, d_info);
         e = hipGetLastError();

@@ -434,7 +434,9 @@ int ensure_prepared(rb_engine* e) {
                 rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
                                                e->fast_slots.ptr, &info, e->stream,
                                                (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
-                if (rc) return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+                if (rc && rc != static_cast<int>(hipErrorNotReady))
+                    return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+                if (rc) info.depth = 0xFFFFFFFFu;  // clustering did not converge within its round limit: host builder
                 // a tree deeper than the LDS stack spills to a global scratch column per lane, which only the
                 // persistent kernels (bounded grid) get; otherwise use the depth-limited host builder
                 const uint32_t kern = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;

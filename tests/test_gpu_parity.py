@@ -376,3 +376,27 @@ def test_sphere_bvh_under_poor_conditioning(n, extent, camscale):
     _, b, st2 = _hip(s, abi.KERNEL_STREAM, stats=False, no_sphere_bvh=True)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert st["segments"] == st2["segments"]
+
+
+@pytest.mark.parametrize("kw,builder", [(dict(fast_bvh=True), "host-sah"), (dict(device_bvh=True), "device-ploc"),
+                                        (dict(device_lbvh=True), "device-lbvh")])
+def test_coincident_triangles(kw, builder):
+    # 2 500 copies of one triangle (identical boxes, identical Morton codes, identical t for every ray)
+    # in front of a wall: the builders must terminate on the run of duplicates, and the winner among the
+    # copies is the first one in the reference's visit order
+    tri = ((-1.0, 0.5, -3.0), (1.0, 0.5, -3.0), (0.0, 2.0, -3.2))
+    wall = scenes._quad((-3, 0, -5), (3, 0, -5), (3, 4, -5), (-3, 4, -5))
+    groups = [(scenes.material(**scenes.RED), [tri] * 2500), (scenes.material(**scenes.KHAKI), wall),
+              (scenes.material(**scenes.LIGHT), scenes._quad((-1, 3.9, -4), (1, 3.9, -4), (1, 3.9, -2), (-1, 3.9, -2)))]
+    u = scenes.make_uniforms(40, 30, 2, 4, cam_pos=(0, 1.5, 2), cam_dir=(0, 0, -1), ground_enabled=1, ground_height=0.0,
+                             sky=(0.3, 0.4, 0.5), color_hash=1)
+    s = scenes._finish("coincident", u, np.zeros(0, abi.SPHERE), np.zeros(0, abi.POINT_LIGHT), groups)
+    assert len(s.bvh_nodes) > 1
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    eng = Engine.new(rc, **kw)
+    frame = eng.render(rc)
+    acc = eng.read_accumulation()
+    assert eng.fast_bvh_builder()[0] == builder
+    eng.close()
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(frame.pixels, o_rgba)

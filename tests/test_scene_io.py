@@ -444,3 +444,21 @@ def test_deep_device_tree_with_the_other_dispatch_shapes(kernel, builder):
     assert e.fast_bvh_builder()[0] == builder
     e.close()
     assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)
+
+
+def test_reference_benchmark_scene_file_loads():
+    # the scene file the reference's own benchmark mode renders (control_plane/modes/benchmark.rs):
+    # 16 624 textured triangles and a point light, 512 x 512.  Dev container only -- the file is not copied.
+    root = "/root/reference/included"
+    path = os.path.join(root, "fixtures", "benchmark.json")
+    if not os.path.isfile(path):
+        pytest.skip("reference checkout not present")
+    s = scene_io.load_scene(path, included_root=root)
+    u = s.uniforms[0]
+    assert (len(s.bvh_triangles), len(s.meshes), len(s.lights), len(s.spheres)) == (16624, 1, 1, 0)
+    assert (u["width"], u["height"], u["total_samples"], u["color_hash_enabled"]) == (512, 512, 1, 1)
+    assert len(s.textures) == 1 and s.meshes[0]["material"]["texture_index"] == 0
+    np.testing.assert_allclose(s.lights[0]["material"]["emissive"], [100, 100, 100])
+    small = s.with_params(width=24, height=24, spp=1)
+    acc, _, rgba, st = _oracle.render(small)
+    assert st["mesh_hits"] > 0 and rgba.shape == (24, 24, 4)

@@ -6,7 +6,7 @@ Workload (BASELINE.json configs[1], "C2"): the seeded procedural Cornell box
 1920x1080, 1024 spp, max_depth 8.  A *step* is one full render of that frame:
 every pixel accumulates all 1024 samples, with the scene already resident in HBM
 (the (pixel, sample) stream is cut into a few launches of the trace kernel so its
-per-path colour buffer stays within a 4 GiB budget: `roofline.launches_per_step`).  metric = Msamples/s where a sample is one
+per-path colour buffer stays within a 40 GiB budget (C2: one launch): `roofline.launches_per_step`).  metric = Msamples/s where a sample is one
 ray segment (one executed iteration of the bounce loop, shader.wgsl:534),
 counted on the device and equal to the oracle's count.
 

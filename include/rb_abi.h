@@ -216,7 +216,7 @@ typedef struct rb_options {
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
     uint32_t _reserved[5];      /* tuning / ablation knobs, 0 = default: [0] persistent blocks per CU, [1] colour-buffer
-                                   budget in MiB (4096), [2] queue batch, [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
+                                   budget in MiB (40960), [2] queue batch, [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
 } rb_options;
 
 enum {

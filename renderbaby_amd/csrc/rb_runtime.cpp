@@ -590,11 +590,12 @@ int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
     if (kernel == RB_KERNEL_STREAM) {
         // One float4 per (pixel, sample) of a launch chunk.  Keep the item count below 2^31
-        // and, unless the caller fixed the chunk, the buffer within a budget (default 4 GiB:
-        // small against 288 GB of HBM, large enough that launch boundaries do not matter).
+        // and, unless the caller fixed the chunk, the buffer within a budget (default 40 GiB of the
+        // 288 GB of HBM: the whole C2 frame -- 1024 spp, 34 GB -- is then one launch; 32 / 8 / 2 / 1
+        // launches per frame measured 23.5 / 24.6 / 24.7 / 24.7 G segments/s).
         const uint64_t tiles = static_cast<uint64_t>((e->width + 7) / 8) * ((e->local_rows + 7) / 8);
         const uint64_t per_pass = tiles * 64ull * e->prh.samples_per_pass;  // items per pass
-        const uint64_t budget_items = (e->opt._reserved[1] ? static_cast<uint64_t>(e->opt._reserved[1]) : 4096ull) * (1ull << 20) / 16ull;
+        const uint64_t budget_items = (e->opt._reserved[1] ? static_cast<uint64_t>(e->opt._reserved[1]) : 40960ull) * (1ull << 20) / 16ull;
         uint64_t max_chunk = std::min<uint64_t>((1ull << 31) / std::max<uint64_t>(per_pass, 1) , 0xFFFFFFFFull);
         if (!e->opt.passes_per_launch) max_chunk = std::min(max_chunk, std::max<uint64_t>(budget_items / std::max<uint64_t>(per_pass, 1), 1));
         if (max_chunk == 0) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame too large for one launch");

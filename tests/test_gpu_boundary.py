@@ -211,3 +211,20 @@ def test_iterator_delivering_every_n_passes():
     it = eng.frame_iterator(RenderConfig.from_scene(s, create=False))
     assert len([1 for _ in it]) == 7
     eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(fast_bvh=True), dict(device_bvh=True), dict()], ids=["host-sah", "device-ploc", "exact"])
+def test_scene_updates_rebuild_the_library_trees(kw):
+    # Change::Update of the BVH / triangle / sphere fields must rebuild everything derived from them:
+    # prepared triangles, the opt-in walk's tree (host or device built), the sphere tree
+    a = scenes.mesh_scene(24, 24, 40, 30, 2, 4, seed=3)
+    b = scenes.mesh_scene(30, 20, 40, 30, 2, 4, seed=9)
+    c = scenes.spheres_scene(n=3000, width=40, height=30, spp=2, max_depth=4, extent=10.0)
+    d = scenes.spheres_scene(n=40, width=40, height=30, spp=2, max_depth=4, extent=3.0)      # below the tree threshold
+    eng = Engine.new(RenderConfig.from_scene(a), **kw)
+    for i, s in enumerate((a, b, c, a, d, c)):
+        rc = RenderConfig.from_scene(s, create=(i == 0))
+        frame = eng.render(rc)
+        assert np.array_equal(frame.pixels, _oracle.render(s)[2]), i
+        assert np.array_equal(eng.read_accumulation().view(np.uint32), _oracle.render(s)[0].view(np.uint32)), i
+    eng.close()

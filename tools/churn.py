@@ -1,0 +1,13 @@
+import sys, os, resource; sys.path.insert(0,'/root/repo')
+from renderbaby_amd import Engine, RenderConfig, scenes
+s = scenes.cornell(16, 12, 1, 2); rc = RenderConfig.from_scene(s)
+m = scenes.mesh_scene(24, 24, 16, 12, 1, 2); rcm = RenderConfig.from_scene(m)
+def fds(): return len(os.listdir('/proc/self/fd'))
+def thr(): return len(os.listdir('/proc/self/task'))
+for i in range(20000):
+    e = Engine.new(rc); e.render(rc); e.close()
+    if i % 4 == 0:
+        e = Engine.new(rcm, device_bvh=True); e.render(rcm); e.close()
+    if i % 1000 == 0:
+        print(i, "rss MB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024, "fds", fds(), "threads", thr(), flush=True)
+print("done")

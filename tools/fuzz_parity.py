@@ -1,0 +1,122 @@
+"""Differential fuzzing of the HIP kernels against the CPU oracle: random small scenes (random cameras,
+sphere / triangle soups with nasty cases -- tiny, huge, degenerate, coincident, axis-aligned -- random
+materials, lights, ground, textures, colour hash), every kernel variant, bit for bit.
+
+    python tools/fuzz_parity.py [first_seed] [count]
+"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from renderbaby_amd import Engine, RenderConfig, abi, scenes
+from tests import _oracle
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(1, 28)), int(rng.integers(1, 20))
+    spp, depth = int(rng.integers(1, 4)), int(rng.integers(0, 9))
+    f = lambda lo, hi, n=None: np.float32(rng.uniform(lo, hi)) if n is None else rng.uniform(lo, hi, n).astype(np.float32)
+    # camera: sometimes axis-aligned (zero direction components -> infinities in 1/dir)
+    cam_pos = f(-4, 4, 3)
+    cam_dir = f(-1, 1, 3)
+    if rng.random() < 0.3:
+        cam_dir = np.array([(0, 0, -1), (0, -1, 0), (1, 0, 0), (0, 0.0001, -1)][int(rng.integers(0, 4))], np.float32)
+    if not np.any(cam_dir):
+        cam_dir = np.array([0, 0, -1], np.float32)
+    u = scenes.make_uniforms(w, h, spp, depth, cam_pos=cam_pos, cam_dir=cam_dir,
+                             pane_distance=float(f(0.5, 60)), pane_width=float(f(1, 80)),
+                             ground_enabled=int(rng.integers(0, 2)), ground_height=float(f(-3, 1)),
+                             checkerboard_enabled=int(rng.integers(0, 2)), sky=f(0, 1, 3), color_hash=int(rng.integers(0, 2)),
+                             cb1=f(0, 1, 3), cb2=f(0, 1, 3))
+    presets = ["plastic", "metal", "mirror", "light"]
+    # spheres: none, a few (linear scan) or many (sphere tree)
+    ns = int(rng.choice([0, 1, 5, 40, 90, 400]))
+    sp = np.zeros(ns, abi.SPHERE)
+    for i in range(ns):
+        sp[i]["center"] = f(-6, 6, 3)
+        sp[i]["radius"] = float(rng.choice([1e-4, 0.05, 0.4, 1.5, 30.0])) * float(f(0.5, 1.5))
+        sp[i]["material"] = scenes.sphere_material(presets[int(rng.integers(0, 4))], f(0, 1, 3))
+        if rng.random() < 0.2:
+            sp[i]["material"]["shininess"] = float(f(0, 1200))
+    nl = int(rng.choice([0, 0, 1, 3]))
+    lights = np.zeros(nl, abi.POINT_LIGHT)
+    for i in range(nl):
+        lights[i]["center"], lights[i]["radius"] = f(-5, 5, 3), 0.5
+        lights[i]["material"] = scenes.material(diffuse=(0, 0, 0), specular=(0, 0, 0), shininess=0.0, emissive=f(0, 40, 3), illum=0)
+    # triangles: none, a handful (single node), a few hundred (LDS / multi-node), a few thousand
+    nt = int(rng.choice([0, 3, 40, 130, 300, 1500]))
+    groups, uv_groups, tex = [], [], []
+    if nt:
+        use_tex = rng.random() < 0.4
+        if use_tex:
+            tex = [scenes.checker_texture()]
+        ngroups = int(rng.integers(1, 4))
+        per = max(nt // ngroups, 1)
+        for g in range(ngroups):
+            tris, uvs = [], []
+            for _ in range(per):
+                kind = rng.random()
+                c = f(-5, 5, 3)
+                if kind < 0.1:      # degenerate: zero area
+                    v = [c, c, c + f(-1, 1, 3)]
+                elif kind < 0.2:    # huge
+                    v = [c + f(-40, 40, 3) for _ in range(3)]
+                elif kind < 0.3:    # tiny
+                    v = [c + f(-1e-3, 1e-3, 3) for _ in range(3)]
+                elif kind < 0.4:    # axis-aligned in a plane
+                    v = [c + np.array([0, a, b], np.float32) for a, b in ((0, 0), (1, 0), (0, 1))]
+                else:
+                    v = [c + f(-0.7, 0.7, 3) for _ in range(3)]
+                tris.append(tuple(tuple(map(float, p)) for p in v))
+                uvs.append([tuple(map(float, f(-2, 2, 2))) for _ in range(3)])
+            if g == 0 and per > 4:  # coincident copies
+                tris[1] = tris[0]; tris[2] = tris[0]
+            m = scenes.material(diffuse=f(0, 1, 3), specular=f(0, 1, 3) * (rng.random() < 0.5), shininess=float(f(0, 1100)),
+                                emissive=f(0, 5, 3) * (rng.random() < 0.3), texture_index=0 if (use_tex and g == 0) else -1)
+            groups.append((m, tris)); uv_groups.append(uvs)
+    return scenes._finish(f"fuzz{seed}", u, sp, lights, groups, uv_groups, tex)
+
+
+def variants(scene):
+    v = [("pixel", dict(kernel=abi.KERNEL_PIXEL)), ("queue", dict(kernel=abi.KERNEL_QUEUE)), ("stream", dict())]
+    if len(scene.bvh_nodes) > 1:
+        v += [("stream-noLDS", dict(lds_mode=1)), ("stream-perseg", dict(no_leaf_stepping=True)), ("fast", dict(fast_bvh=True)),
+              ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
+    if len(scene.spheres) > 64:
+        v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True))]
+    return v
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad = 0
+    trace = open(os.environ["FUZZ_TRACE"], "w") if os.environ.get("FUZZ_TRACE") else None   # last (seed, variant) started
+    for seed in range(first, first + count):
+        s = random_scene(seed)
+        o_acc, _, o_rgba, o_st = _oracle.render(s)
+        rc = RenderConfig.from_scene(s)
+        for name, kw in variants(s):
+            if trace is not None:
+                trace.seek(0); trace.truncate(); trace.write(f"{seed} {name}\n"); trace.flush()
+            try:
+                e = Engine.new(rc, stats=True, **kw)
+                frame = e.render(rc); acc = e.read_accumulation(); st = e.stats(); e.close()
+            except Exception as ex:   # a scene the library refuses must be refused by every variant alike
+                print(f"seed {seed} {name}: {type(ex).__name__}: {ex}"); bad += 1; continue
+            ok = np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(frame.pixels, o_rgba) \
+                and st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"]
+            if not ok:
+                bad += 1
+                nd = int((acc.view(np.uint32) != o_acc.view(np.uint32)).any(axis=-1).sum())
+                print(f"seed {seed} {name}: MISMATCH ({nd} pixels; segments {st['segments']} vs {o_st['segments']}) "
+                      f"[{s.width}x{s.height} spp {s.total_samples} depth {int(s.uniforms[0]['max_depth'])} tris {len(s.bvh_triangles)} "
+                      f"nodes {len(s.bvh_nodes)} spheres {len(s.spheres)} lights {len(s.lights)}]")
+        if (seed - first) % 20 == 19:
+            print(f"... {seed - first + 1} scenes, {bad} failures so far", flush=True)
+    print(f"fuzz: {count} scenes from seed {first}: {bad} failures")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -497,21 +497,22 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
             hipLaunchKernelGGL(k_ploc_commit, dim3(1), dim3(1), 0, stream, counters);
             std::swap(A, B);
             if ((round & 3) == 3 || live <= 4096u) {  // tighten the bound now and then (one 4-byte read-back)
-                e = hipMemcpyAsync(&live, counters, 4, hipMemcpyDeviceToHost, stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                e = hipStreamSynchronize(stream);
+                if (e == hipSuccess) e = hipMemcpy(&live, counters, 4, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) return done(e);
             }
         }
         if (live > 1u) {  // not reached in practice (every round merges at least the closest pair)
-            e = hipMemcpyAsync(&live, counters, 4, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) e = hipMemcpy(&live, counters, 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) return done(e);
             if (live > 1u) return done(hipErrorNotReady);  // the caller falls back to the host builder
         }
         hipLaunchKernelGGL(k_ploc_finish, dim3(1), dim3(1), 0, stream, A, bounds, d_info);
         e = hipGetLastError();
         if (e != hipSuccess) return done(e);
-        e = hipMemcpyAsync(info_out, d_info, sizeof(DeviceTreeInfo), hipMemcpyDeviceToHost, stream);
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = hipMemcpy(info_out, d_info, sizeof(DeviceTreeInfo), hipMemcpyDeviceToHost);
         return done(e);
     }
     hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, stream, keys, n, left, right, rfirst, rsize, parent, leafpar);
@@ -521,7 +522,8 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
                        nmin, nmax, bounds, nodes_out, fast_slots_out, d_info);
     e = hipGetLastError();
     if (e != hipSuccess) return done(e);
-    e = hipMemcpyAsync(info_out, d_info, sizeof(DeviceTreeInfo), hipMemcpyDeviceToHost, stream);
+    e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipMemcpy(info_out, d_info, sizeof(DeviceTreeInfo), hipMemcpyDeviceToHost);
     return done(e);
 }
 

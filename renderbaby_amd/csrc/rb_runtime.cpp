@@ -642,12 +642,11 @@ int read_rgba(rb_engine* e, uint8_t* out) {
     if (!out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
     const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
     const size_t row_bytes = static_cast<size_t>(e->width) * 4;
-    if (sc == 1) {
-        HIP_TRY(e, hipMemcpyAsync(out, e->out_rgba.ptr, row_bytes * e->height, hipMemcpyDeviceToHost, e->stream));
-    } else {
-        HIP_TRY(e, hipMemcpyAsync(out, e->out_rgba.ptr, row_bytes * e->padded_rows, hipMemcpyDeviceToHost, e->stream));
-    }
+    // The destination is caller-owned, normally pageable memory: finish the stream's work, then a
+    // blocking copy.  (An async copy into pageable memory followed by a stream wait leaves it to the
+    // runtime when the bytes reach the caller's buffer.)
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out, e->out_rgba.ptr, row_bytes * (sc == 1 ? e->height : e->padded_rows), hipMemcpyDeviceToHost));
     return RB_OK;
 }
 
@@ -925,8 +924,8 @@ int rb_read_accumulation(rb_engine* e, float* accum_out) {
     if (rc) return rc;
     if (!accum_out) return fail(e, RB_ERR_NULL_ARGUMENT, "accum_out is NULL");
     const uint32_t rows = (e->opt.shard_count > 1) ? e->padded_rows : e->height;
-    HIP_TRY(e, hipMemcpyAsync(accum_out, e->accum.ptr, static_cast<size_t>(e->width) * rows * 16, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(accum_out, e->accum.ptr, static_cast<size_t>(e->width) * rows * 16, hipMemcpyDeviceToHost));
     return RB_OK;
 }
 

@@ -671,7 +671,7 @@ int accumulate_timing(rb_engine* e) {
     return RB_OK;
 }
 
-int update_locked(rb_engine* e, const rb_config* cfg) {
+int update_fields(rb_engine* e, const rb_config* cfg) {
     int rc = check_fields(e, cfg);
     if (rc) return rc;
     const bool first = !e->initialized;
@@ -704,9 +704,18 @@ int update_locked(rb_engine* e, const rb_config* cfg) {
     rc = validate_scene(e, cfg);
     if (rc) return rc;
     e->initialized = true;
-    // inputs are borrowed only for this call.  (Without Create/Update uniforms the reference
-    // panics at the next use, gpu_wrapper.rs:303-329; here that is require_ready's error.)
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RB_OK;
+}
+
+// Inputs are borrowed only for this call: whatever update_fields has queued from the caller's
+// buffers must have left them before we return -- also when it stops half-way with an error.
+// (Without Create/Update uniforms the reference panics at the next use, gpu_wrapper.rs:303-329;
+// here that is require_ready's error.)
+int update_locked(rb_engine* e, const rb_config* cfg) {
+    const int rc = update_fields(e, cfg);
+    const hipError_t st = hipStreamSynchronize(e->stream);
+    if (rc) return rc;
+    if (st != hipSuccess) return fail(e, RB_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(st));
     return RB_OK;
 }
 

@@ -13,8 +13,9 @@ from tests import _oracle
 
 def random_scene(seed):
     rng = np.random.default_rng(seed)
-    w, h = int(rng.integers(1, 28)), int(rng.integers(1, 20))
-    spp, depth = int(rng.integers(1, 4)), int(rng.integers(0, 9))
+    big = bool(os.environ.get("FUZZ_BIG"))   # larger frames / more samples: several queue reservations per wave
+    w, h = int(rng.integers(1, 300 if big else 28)), int(rng.integers(1, 200 if big else 20))
+    spp, depth = int(rng.integers(1, 10 if big else 4)), int(rng.integers(0, 9))
     f = lambda lo, hi, n=None: np.float32(rng.uniform(lo, hi)) if n is None else rng.uniform(lo, hi, n).astype(np.float32)
     # camera: sometimes axis-aligned (zero direction components -> infinities in 1/dir)
     cam_pos = f(-4, 4, 3)

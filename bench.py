@@ -84,7 +84,7 @@ def cpu_baseline(scene, budget_s):
     on a bounded sample of the same workload: the full frame at n spp, n chosen to
     fill about `budget_s` seconds."""
     from tests import _oracle
-    cores = _oracle.lib().rbo_max_threads()
+    cores = _oracle.cpu_share()   # threads actually used: the CPUs this process is granted, not the ones it can see
     h, w = scene.height, scene.width
     # Grow a centred window of ONE pass until it takes long enough to time (some workloads, e.g.
     # C4's 10^6-sphere linear scan, cannot afford a whole pass); then either extend to several

@@ -127,9 +127,34 @@ class OracleScene:
         self.c = s
 
 
+def cpu_share():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota (a
+    GPU box shows 256 logical CPUs but grants 16 of them; running one thread per visible CPU there
+    just gets the pool throttled)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, lib().rbo_max_threads()))
+
+
 def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0, samples_per_pass=1, cols=None):
-    """Returns (accum[h,w,4] f32, output[h,w] u32 packed shader order, rgba[h,w,4] mirrored, stats dict)."""
+    """Returns (accum[h,w,4] f32, output[h,w] u32 packed shader order, rgba[h,w,4] mirrored, stats dict).
+    threads = 0: one per CPU this process may use (cpu_share)."""
     L = lib()
+    if threads <= 0:
+        threads = cpu_share()
     os_ = OracleScene(scene, samples_per_pass)
     w, h = scene.width, scene.height
     if n_passes is None:

@@ -8,14 +8,21 @@ OUT      := renderbaby_amd/librenderbaby_hip.so
 # Numerics contract: no FMA contraction, correctly rounded / and sqrt, no fast-math.
 NUMERICS := -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -Wall -Wno-unused-function
-SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_build.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp
+SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_build.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp $(CSRC)/rb_rccl.cpp
 HDRS     := $(CSRC)/rb_internal.hpp $(CSRC)/rb_device_common.hpp $(CSRC)/rb_device_math.hpp \
-            $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp include/rb_abi.h
+            $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp $(CSRC)/rb_rccl.hpp include/rb_abi.h
+OBJS     := $(patsubst $(CSRC)/%,build/obj/%.o,$(SRCS))
 
 all: $(OUT) oracle
 
-$(OUT): $(SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+# one object per source (the kernel TU takes a minute, the host files seconds).  RCCL is loaded with dlopen
+# when a multi-device engine is first made (rb_rccl.cpp): no link-time dependency on librccl.
+build/obj/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(OUT): $(OBJS)
+	$(HIPCC) -fPIC --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -5,19 +5,29 @@ Workload (BASELINE.json configs[1], "C2"): the seeded procedural Cornell box
 (12 triangles incl. the emissive ceiling quad, 8 spheres, 0 point lights),
 1920x1080, 1024 spp, max_depth 8.  A *step* is one full render of that frame:
 every pixel accumulates all 1024 samples, with the scene already resident in HBM
-(the (pixel, sample) stream is cut into a few launches of the trace kernel so its
-per-path colour buffer stays within a 40 GiB budget (C2: one launch): `roofline.launches_per_step`).  metric = Msamples/s where a sample is one
-ray segment (one executed iteration of the bounce loop, shader.wgsl:534),
-counted on the device and equal to the oracle's count.
+(the (pixel, sample) stream is cut into launches of the trace kernel so that its
+per-path colour buffer stays within the library's budget: `roofline.launches_per_step`).
+metric = Msamples/s where a sample is one ray segment (one executed iteration of the
+bounce loop, shader.wgsl:534), counted on the device and equal to the oracle's count.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's rows
-are sharded in interleaved stripes, every rank renders all samples of its rows,
-and one RCCL gather moves the RGBA8 rows to rank 0 inside the timed region
-("scaling": "strong" -- the total work is the same frame for every N).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's rows are
+sharded in interleaved stripes, every rank renders all samples of its rows, and ONE
+RCCL gather inside librenderbaby_hip.so (rb_comm_init_rank: grouped ncclSend / ncclRecv)
+moves the RGBA8 rows to rank 0, which de-interleaves and reads the frame back -- all inside
+the timed region ("scaling": "strong" -- the total work is the same frame for every N).
+torch.distributed only distributes the communicator id and reduces the timings.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3]
+`roofline` reports the ceiling that binds the dominant (trace) kernel -- VALU issue for the
+Cornell / own-tree / sphere kernels, L2 bandwidth for the reference walk -- from per-segment
+constants of a rocprofv3 PMC profile of THIS build (profiles/*_pmc.json, stamped with the
+source fingerprint; a profile of another build is refused), times the segment rate measured
+here.  SURVEY.md section 8(d)'s algorithmic-bytes figure and the measured HBM traffic are
+reported beside it (`roofline.algorithmic`, `roofline.hbm`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4|c5|lamp]
 """
 import argparse
+import glob
 import json
 import os
 import subprocess
@@ -28,7 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy); 256 CUs x 4 SIMDs, a wave64 VALU
+# instruction issues over 2 cycles on a SIMD-32 at up to 2.4 GHz; aggregate L2 ~34.5 TB/s
+HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0      # 1228.8 G wave-instructions/s
+L2_PEAK_GBPS = 34500.0
 
 
 def parse():
@@ -41,14 +55,27 @@ def parse():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--stripe-rows", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.achieved = null)")
-    ap.add_argument("--fast-bvh", action="store_true", help="RB_FLAG_FAST_BVH (multi-node meshes; see DESIGN.md)")
-    ap.add_argument("--device-bvh", action="store_true", help="RB_FLAG_DEVICE_BVH: build the fast walk's tree on the GPU")
+    ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.algorithmic = null)")
+    ap.add_argument("--walk", default="", choices=["", "reference", "own", "own-host", "own-device"],
+                    help="multi-node meshes: the reference walk or the library's own tree (default: the library's default)")
+    ap.add_argument("--fast-bvh", action="store_true", help="same as --walk own-host")
+    ap.add_argument("--device-bvh", action="store_true", help="same as --walk own-device")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --same-device) rehearses the N>1 path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--color-budget-mib", type=int, default=0, help="colour-buffer budget of the stream kernels (0 = library default)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last assembled RGBA8 frame to this .npy")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.fast_bvh:
+        a.walk = "own-host"
+    if a.device_bvh:
+        a.walk = "own-device"
+    return a
+
+
+def walk_kwargs(walk):
+    return {"": {}, "reference": dict(reference_walk=True), "own": dict(own_tree=True), "own-host": dict(host_bvh=True),
+            "own-device": dict(device_bvh=True)}[walk]
 
 
 def make_scene(name, spp):
@@ -141,18 +168,25 @@ def measured_copy_bandwidth(device):
     return 2.0 * n * reps / dt / 1e9
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic_*.json), or None."""
-    import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
+def load_pmc(key, kernel_name, fingerprint):
+    """Per-segment constants of the dominant kernel from the rocprofv3 PMC profile of this build
+    (tools/profile_bench.sh -> profiles/<tag>_<key>_pmc.json).  -> (dict | None, note)."""
+    stale = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{key}_pmc.json")), reverse=True):
         try:
             d = json.load(open(p))
         except Exception:
             continue
-        if d.get("workload") == workload:
-            best = d
-    return best
+        if d.get("kernel") != kernel_name:
+            continue
+        if d.get("source_fingerprint") != fingerprint:
+            stale = stale or os.path.relpath(p, ROOT)
+            continue
+        d["_path"] = os.path.relpath(p, ROOT)
+        return d, None
+    if stale:
+        return None, f"{stale} was taken on a different build (source fingerprint differs from {fingerprint}): refused"
+    return None, f"no PMC profile of this build for '{key}' under profiles/ (tools/profile_bench.sh)"
 
 
 def main():
@@ -182,11 +216,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     red_dev = f"cuda:{local_rank}" if a.backend == "nccl" else "cpu"
 
-    from renderbaby_amd import abi, engine
+    from renderbaby_amd import _lib, abi, engine
     from renderbaby_amd.dist import ShardedRenderer
 
     scene, desc = make_scene(a.workload, a.spp)
     spp = scene.total_samples
+    wkw = walk_kwargs(a.walk)
 
     def barrier():
         if world > 1:
@@ -196,14 +231,17 @@ def main():
     # ---- instrumented pass (untimed): work counters for the algorithmic-bytes figure
     stats = None
     if not a.no_stats:
-        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True, fast_bvh=a.fast_bvh, device_bvh=a.device_bvh)
+        r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel, stats=True,
+                            color_budget_mib=a.color_budget_mib, **wkw)
         r.engine.reset_stats()
         r.render_local()
         stats = r.engine.stats()
         r.close()
 
+    # the gather runs inside the library (RCCL) unless this is the gloo rehearsal on one device
     r = ShardedRenderer(scene, rank, world, local_rank, a.stripe_rows, kernel=a.kernel,
-                        host_gather=(a.backend != "nccl"), fast_bvh=a.fast_bvh, device_bvh=a.device_bvh)
+                        host_gather=(a.backend != "nccl"), library_gather=(a.backend == "nccl" and world > 1),
+                        color_budget_mib=a.color_budget_mib, **wkw)
     for _ in range(a.warmup):
         r.step()
     r.engine.reset_stats()
@@ -231,48 +269,56 @@ def main():
 
     if rank == 0 and a.dump_frame and frame is not None:
         import numpy as np
-        np.save(a.dump_frame, frame.cpu().numpy())
+        np.save(a.dump_frame, frame if isinstance(frame, np.ndarray) else frame.cpu().numpy())
     if rank == 0:
         value = seg_total * a.steps / elapsed / 1e6
-        # dominant kernel: the trace kernel.  A step is `launches` launches of it (the (pixel,
-        # sample) stream is cut so the colour buffer stays within its budget); duration per
-        # launch from HIP events recorded around each launch on the engine's stream.
+        # dominant kernel: the trace kernel.  A step is `launches` launches of it; duration per launch
+        # from HIP events recorded around each launch on the engine's stream.
         launches = max(int(st["launches"]) // max(a.steps, 1), 1)
         trace_ms_step = st["trace_ms"] / max(a.steps, 1)
         k_ms = trace_ms_step / launches
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
+        seg_rate = seg_per_step / (trace_ms_step * 1e-3) if trace_ms_step > 0 else 0.0   # this rank's segments/s inside the trace kernel
+        fingerprint = _lib.source_fingerprint()
+        key = a.workload + ("" if not a.walk else "_" + a.walk.replace("-", ""))
+        pmc, pmc_note = load_pmc(key, kernel_name, fingerprint)
+        roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "kernel": kernel_name + "<false>", "kernel_ms": k_ms, "launches_per_step": launches,
+                "accumulate_ms_per_step": st["accumulate_ms"] / max(a.steps, 1), "source_fingerprint": fingerprint}
+        if pmc is not None:
+            c = pmc["per_segment"]
+            valu = {"achieved": c["valu_instr"] * seg_rate / 1e9, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                    "instr_per_segment": c["valu_instr"], "lane_utilisation": pmc["derived"].get("valu_lane_utilisation"),
+                    "wait_any_frac": pmc["derived"].get("wait_any_frac"), "clock_GHz": pmc["derived"].get("clock_GHz")}
+            valu["frac"] = valu["achieved"] / valu["peak"]
+            hbm = {"achieved": c["hbm_bytes"] * seg_rate / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+            hbm["frac"] = hbm["achieved"] / hbm["peak"]
+            l2 = None
+            if c.get("l2_bytes") is not None:
+                l2 = {"achieved": c["l2_bytes"] * seg_rate / 1e9, "peak": L2_PEAK_GBPS, "unit": "GB/s",
+                      "l1_accesses_per_segment": c.get("tcp_accesses")}
+                l2["frac"] = l2["achieved"] / l2["peak"]
+            # the binding ceiling = the largest of the fractions
+            cands = [("valu", valu)] + ([("l2", l2)] if l2 else []) + [("hbm", hbm)]
+            bound, top = max(cands, key=lambda kv: kv[1]["frac"])
+            roof.update({"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                         "frac": top["frac"], "traffic": c["hbm_bytes"] * seg_per_step / launches,
+                         "valu": valu, "hbm": hbm, "l2": l2, "pmc_profile": pmc["_path"]})
+        else:
+            roof["note"] = pmc_note
         if stats is not None and k_ms > 0:
-            owned, padded = r.owned, r.padded
+            owned = r.owned
             algo_step = abi.algorithmic_bytes(stats, owned * scene.width * launches, resumed=False)
             algo = algo_step / launches
-            roof["achieved"] = algo / (k_ms * 1e-3) / 1e9
-            roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS
-            roof["algorithmic_bytes_per_launch"] = algo
-            roof["bytes_per_segment"] = algo_step / max(stats["segments"], 1)
-            roof["kernel_ms"] = k_ms
-            roof["kernel"] = kernel_name + "<false>"
-            roof["launches_per_step"] = launches
-            roof["accumulate_ms_per_step"] = st["accumulate_ms"] / max(a.steps, 1)
-            roof["note"] = ("algorithmic bytes / launch time; it can exceed the HBM peak because scene data is "
-                            "served from the scalar cache / L1 / L2; `traffic` is what the PMC counters see in HBM")
-        # what actually bounds the trace kernel (VALU issue): PMC numbers of the same kernel on the
-        # same scene, collected by rocprofv3 in a separate profiled run (profiles/*_final_pmc.json)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_64spp_final_pmc.json")))["derived"]
-            if a.workload == "c2":
-                roof["valu"] = {"instr_per_64_segments": pmc["valu_instr_per_wave_iteration"],
-                                "lane_utilisation": pmc["valu_lane_utilisation"], "clock_GHz": pmc["clock_GHz"],
-                                "source": "profiles/r01_c2_64spp_final_pmc.json"}
-        except Exception:
-            pass
+            roof["algorithmic"] = {"bytes_per_launch": algo, "bytes_per_segment": algo_step / max(stats["segments"], 1),
+                                   "GBps": algo / (k_ms * 1e-3) / 1e9,
+                                   "note": "SURVEY.md 8(d) logical bytes / launch time; served from the scalar cache / L1 / L2, "
+                                           "so it is not a fraction of any one ceiling"}
+            roof["work_per_segment"] = {k: stats[k] / max(stats["segments"], 1)
+                                        for k in ("nodes_popped", "tris_tested", "spheres_tested", "lights_tested", "mesh_hits")}
         try:
             roof["measured_copy_peak"] = measured_copy_bandwidth(f"cuda:{local_rank}")  # GB/s, read + write
         except Exception:
             pass
-        tr = load_traffic(a.workload)
-        if tr is not None:
-            roof["traffic"] = tr.get("hbm_bytes_per_launch")
-            roof["traffic_source"] = tr.get("source")
         cpu = None
         if a.cpu_seconds > 0 and world == 1:
             cpu = cpu_baseline(scene, a.cpu_seconds)
@@ -284,8 +330,10 @@ def main():
             "config": {"workload": desc, "width": scene.width, "height": scene.height, "spp": spp,
                        "max_depth": int(scene.uniforms["max_depth"][0]), "segments_per_step": int(seg_total),
                        "paths_per_step": int(paths_total), "Mpaths_per_s": paths_total * a.steps / elapsed / 1e6,
-                       "parallelism": f"row-stripes x{world}" if world > 1 else "single GPU",
-                       "stripe_rows": a.stripe_rows, "device": engine.device_name(local_rank)},
+                       "parallelism": f"row-stripes x{world}, one RCCL gather per frame inside the library" if world > 1 else "single GPU",
+                       "stripe_rows": a.stripe_rows, "walk": a.walk or "library default",
+                       "tree_builder": r.engine.fast_bvh_builder()[0],
+                       "device": engine.device_name(local_rank)},
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms_per_step_median": sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else None,
         }

@@ -216,7 +216,8 @@ typedef struct rb_options {
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
     uint32_t _reserved[5];      /* tuning / ablation knobs, 0 = default: [0] persistent blocks per CU, [1] colour-buffer
-                                   budget in MiB (40960), [2] queue batch, [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
+                                   budget in MiB (default 4096, at most half of the free device memory), [2] queue batch,
+                                   [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
 } rb_options;
 
 enum {
@@ -229,13 +230,19 @@ enum {
 enum {
     RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
-    RB_FLAG_FAST_BVH = 4u, /* opt-in: walk the library's own SAH tree over the triangles (culling, near-first)
-                              and accept a hit only if the reference's traversal would have tested it */
+    RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first)
+                              and accept a hit only if the reference's traversal would have tested it; same frames */
     RB_FLAG_DEVICE_BVH = 8u, /* with RB_FLAG_FAST_BVH: build that tree on the GPU (Morton order + locally-ordered
                                 clustering) instead of on the host (binned SAH): milliseconds instead of ~0.5 s per
                                 million triangles, the same frames */
-    RB_FLAG_DEVICE_LBVH = 16u /* with RB_FLAG_DEVICE_BVH: plain LBVH instead of the clustering (ablation: faster
+    RB_FLAG_DEVICE_LBVH = 16u, /* with RB_FLAG_DEVICE_BVH: plain LBVH instead of the clustering (ablation: faster
                                  build, slower walk) */
+    RB_FLAG_REFERENCE_WALK = 32u, /* multi-node meshes: walk the caller's tree exactly as shader.wgsl:282-392 does
+                                     (128-triangle leaves, no culling) instead of the library's own tree; same frames */
+    RB_FLAG_HOST_BVH = 64u, /* build the library's tree on the host (binned SAH) whatever the triangle count */
+    RB_FLAG_GATHER_PEER_COPY = 128u, /* rb_create_multi: move the stripes with hipMemcpyPeerAsync instead of RCCL
+                                        (hosts without librccl; several shards on one device in the tests) */
+    RB_FLAG_NO_RUN_AHEAD = 256u /* progressive iterator: do not start the next pass while a frame is read back */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.
@@ -267,6 +274,23 @@ typedef struct rb_stats {
  * the first rb_update must again carry Create (gpu_wrapper.rs:117-121). */
 rb_engine* rb_create(const rb_config* cfg);
 rb_engine* rb_create_ex(const rb_config* cfg, const rb_options* opt);
+
+/* The same engine over several devices of this process (the reference has one wgpu
+ * device, gpu_device.rs:27-70): the frame's rows are sharded in interleaved stripes (stripe s -> devices[s % n]),
+ * every device renders all samples of its rows with global pixel indices, and each delivered frame is ONE RCCL
+ * gather of the RGBA8 stripes to devices[0] (grouped ncclSend / ncclRecv over a communicator made with
+ * ncclCommInitAll), de-interleaved there and read back -- so rb_render / rb_iter_next return the whole frame,
+ * bit-identical to a single-device engine's.  opt->shard_* must be zero; every other entry point works on the
+ * handle as on a single-device engine (statistics add up over the devices). */
+rb_engine* rb_create_multi(const rb_config* cfg, const rb_options* opt, const int32_t* devices, uint32_t n_devices);
+
+/* One process per device instead: every process creates its shard (rb_create_ex with shard_rank / shard_count),
+ * rank 0 makes an id, the host program hands it to the others (any transport: MPI, a file, torch.distributed)
+ * and all call rb_comm_init_rank.  From then on rb_render / rb_iter_next gather the stripes to rank 0, which
+ * receives the whole frame; on the other ranks rgba_out may be NULL and nothing is written. */
+#define RB_COMM_ID_BYTES 128
+int rb_comm_unique_id(uint8_t id_out[RB_COMM_ID_BYTES]);
+int rb_comm_init_rank(rb_engine* e, const uint8_t id[RB_COMM_ID_BYTES], uint32_t rank, uint32_t nranks);
 
 /* drop(Engine) */
 void rb_destroy(rb_engine* e);

@@ -38,6 +38,9 @@ def load():
     sig = {
         "rb_create": (vp, [P(abi.Config)]),
         "rb_create_ex": (vp, [P(abi.Config), P(abi.Options)]),
+        "rb_create_multi": (vp, [P(abi.Config), P(abi.Options), P(C.c_int32), u32]),
+        "rb_comm_unique_id": (i32, [vp]),
+        "rb_comm_init_rank": (i32, [vp, vp, u32, u32]),
         "rb_destroy": (None, [vp]),
         "rb_update": (i32, [vp, P(abi.Config)]),
         "rb_render": (i32, [vp, vp]),
@@ -79,7 +82,21 @@ def load():
     return lib
 
 
-EXPORTS = ["rb_create", "rb_create_ex", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
+def source_fingerprint():
+    """Short hash of the library's sources (csrc/ + the ABI header): profiles are stamped with it so that a
+    number measured on another build is never quoted for this one."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(_HERE, "csrc")))
+    for name in files:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(os.path.dirname(_HERE), "include", "rb_abi.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_unique_id", "rb_comm_init_rank", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_iter_set_passes_per_frame", "rb_last_error",
            "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
            "rb_device_rgba", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",

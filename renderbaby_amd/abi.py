@@ -65,6 +65,11 @@ FLAG_NO_SPHERE_BVH = 2
 FLAG_FAST_BVH = 4
 FLAG_DEVICE_BVH = 8
 FLAG_DEVICE_LBVH = 16
+FLAG_REFERENCE_WALK = 32
+FLAG_HOST_BVH = 64
+FLAG_GATHER_PEER_COPY = 128
+FLAG_NO_RUN_AHEAD = 256
+COMM_ID_BYTES = 128
 
 
 class Field(C.Structure):

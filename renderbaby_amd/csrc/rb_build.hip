@@ -410,8 +410,8 @@ inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
 
 // All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream_,
-                          bool plain_lbvh) {
+                          SphereNode* nodes_out, FastCone* cones_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out,
+                          void* stream_, bool plain_lbvh) {
     if (n < 2u || n >= (1u << 28)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using key_t = unsigned long long;

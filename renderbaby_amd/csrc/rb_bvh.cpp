@@ -479,6 +479,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     FBuilder fb{bmn, bmx, e1e2, items, out.nodes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
+    out.cones.assign(out.nodes.size(), FastCone{});
     out.slots.resize(n);
     for (size_t i = 0; i < n; ++i) out.slots[i] = slots[items[i]];
     const float dx = smx[0] - smn[0], dy = smx[1] - smn[1], dz = smx[2] - smn[2];

@@ -524,7 +524,7 @@ DEV uint32_t global_row(const KParams& p, uint32_t ly) {
 DEV void store_pixel(const KParams& p, uint32_t x, uint32_t ly, f3 acc, uint32_t total_samples) {
     const size_t li = (size_t)ly * p.u.width + x;
     const float ts = (float)total_samples;
-    reinterpret_cast<float4*>(p.accum)[li] = make_float4(acc.x, acc.y, acc.z, ts);
+    reinterpret_cast<float4*>(p.accum_out)[li] = make_float4(acc.x, acc.y, acc.z, ts);
     const f3 fin = divs(acc, ts);
     const f3 mapped = mk(fin.x / (fin.x + 1.0f), fin.y / (fin.y + 1.0f), fin.z / (fin.z + 1.0f));
     p.out_rgba[(size_t)ly * p.u.width + (p.u.width - 1u - x)] = color_map(mapped);

@@ -44,9 +44,27 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
                       std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
                       float bmax[3]);
 
-// Fast triangle tree (opt-in, rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
+// Walk mode of multi-node meshes when the caller's flags do not say: the library's own tree (true) or the
+// reference walk (false).  RB_FLAG_REFERENCE_WALK / RB_FLAG_FAST_BVH override it per engine.
+#ifndef RB_FAST_WALK_DEFAULT
+#define RB_FAST_WALK_DEFAULT 0
+#endif
+constexpr bool kFastWalkByDefault = RB_FAST_WALK_DEFAULT != 0;
+constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the library's tree is built on the device by default
+
+// Per node of the library's triangle tree, next to its 64-B SphereNode: for each child a cone of the
+// (unoriented) normals of the triangles below it, pre-scaled for the culling margin (rb_device_intersect.hpp,
+// FastWalk::entry): axis * cos(alpha) / Q and tan(alpha), Q = max L^2 / |e1 x e2|.
+struct alignas(16) FastCone {
+    float l[4];
+    float r[4];
+};
+static_assert(sizeof(FastCone) == 32, "FastCone is 32 B");
+
+// The library's own triangle tree (rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
 struct FastTree {
     std::vector<SphereNode> nodes;
+    std::vector<FastCone> cones;       // one per node
     std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
     std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
@@ -69,8 +87,8 @@ struct DeviceTreeInfo {
     float bmin[3], bmax[3];
 };
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream,
-                          bool plain_lbvh);
+                          SphereNode* nodes_out, FastCone* cones_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out,
+                          void* stream, bool plain_lbvh);
 
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {
@@ -114,6 +132,7 @@ struct KParams {
     const rb_texture_info* tex_info;
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
     const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
+    const FastCone* fast_cones;    // per node: the children's normal cones
     const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
     const uint32_t* fast_slots;    // fast-leaf order -> slot
     const uint32_t* slot_meta;     // per slot {reference leaf node, reference rank}
@@ -131,7 +150,8 @@ struct KParams {
     uint32_t sph_root;             // root child reference
     float sph_bmax[3];
     uint32_t _pad_sph;
-    float* accum;                  // local_rows_padded * width * 4
+    const float* accum_in;         // local_rows_padded * width * 4: the accumulation this launch resumes ...
+    float* accum_out;              // ... and the one it writes (the same buffer, or the other frame slot when a pass runs ahead)
     uint32_t* out_rgba;            // local_rows_padded * width, x mirrored
     unsigned long long* counters;  // C_COUNT
     uint32_t* queue;               // work-queue head (RB_KERNEL_QUEUE / RB_KERNEL_STREAM)
@@ -166,6 +186,11 @@ int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint
                      uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
 int launch_prep_materials(void* first_material, uint32_t stride, uint32_t n, void* stream);
 int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out, void* stream);
+// Multi-GPU assembly on the root device: gathered[rank][local row][x] (every rank's padded stripe buffer back to
+// back) -> frame[global row][x]
+int launch_deinterleave(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t padded_rows,
+                        uint32_t stripe_rows, uint32_t shard_count, void* stream);
+size_t max_dynamic_lds(int device);   // hipDeviceAttributeMaxSharedMemoryPerBlock
 int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,
                           uint32_t a_count, unsigned long long* mismatch16, void* stream);
 int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch16, void* stream);

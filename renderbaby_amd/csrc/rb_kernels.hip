@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
     if (active) {
         const Cam cam = make_cam(p);
         const uint32_t pixel_index = y * p.u.width + x;
-        const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * p.u.width + x];
+        const float4 a4 = reinterpret_cast<const float4*>(p.accum_in)[(size_t)ly * p.u.width + x];
         f3 acc = mk(a4.x, a4.y, a4.z);
         uint32_t total = f2u(a4.w);
         for (uint32_t pass = p.first_pass; pass < p.first_pass + p.n_passes; pass++) {
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
                         }
                         if (ok) {
                             pixel_index = y * width + x;
-                            const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * width + x];
+                            const float4 a4 = reinterpret_cast<const float4*>(p.accum_in)[(size_t)ly * width + x];
                             acc = mk(a4.x, a4.y, a4.z);
                             total = f2u(a4.w);
                             sample = 0;
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const KParams p) {
     if (x >= width || ly >= p.local_rows) return;
     if (global_row(p, ly) >= p.u.height) return;
     const uint32_t S = p.n_passes * p.samples_per_pass;
-    const float4 a4 = reinterpret_cast<const float4*>(p.accum)[(size_t)ly * width + x];
+    const float4 a4 = reinterpret_cast<const float4*>(p.accum_in)[(size_t)ly * width + x];
     f3 acc = mk(a4.x, a4.y, a4.z);
     uint32_t total = f2u(a4.w);
     const nt_f4* __restrict__ c = reinterpret_cast<const nt_f4*>(p.colors) + ((size_t)tile * S) * 64u + lane;
@@ -775,6 +775,18 @@ __global__ void k_prep_materials(unsigned char* first_material, uint32_t stride,
 __global__ void k_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) out[j] = ptris[slots[j]];
+}
+
+// Multi-GPU assembly on the root device: every rank's padded stripe buffer arrives
+// back to back in `gathered`; stripe s of the frame belongs to rank s % n, which stores its stripes in order.
+__global__ void __launch_bounds__(256) k_deinterleave(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
+                                                       uint32_t width, uint32_t height, uint32_t padded_rows,
+                                                       uint32_t stripe_rows, uint32_t n) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const uint32_t s = y / stripe_rows, r = y - s * stripe_rows;
+    const uint32_t rank = s % n, local_row = (s / n) * stripe_rows + r;
+    frame[(size_t)y * width + x] = gathered[((size_t)rank * padded_rows + local_row) * width + x];
 }
 
 // Exhaustive check of rcp_newton against the compiler's correctly rounded 1/b: every one of the
@@ -910,7 +922,11 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         const size_t scene_lds = (size_t)p.u.bvh_node_count * 48u + (size_t)p.index_len * 48u;
         Variant v = PLAIN;
         if (multi && p.fast_nodes != nullptr) v = FAST;
-        else if (multi) v = (p.lds_mode != 1u && lds * 4u + scene_lds <= 160u * 1024u) ? BVH_LDS : BVH;
+        else if (multi) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            v = (p.lds_mode != 1u && lds * 4u + scene_lds <= max_dynamic_lds(dev)) ? BVH_LDS : BVH;
+        }
         else if (p.sph_nodes != nullptr && !p.no_leaf_stepping) v = SPH;
         static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph"};
         li.kernel_name = names[v];
@@ -947,10 +963,11 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
                 else hipLaunchKernelGGL(k_trace_fast<false>, grid, block, lds, stream, q);
                 break;
             case BVH_LDS:
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<true, true, 1024u>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<false, true, 1024u>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
+                e = stats ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<true, true, 1024u>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_bvh<false, true, 1024u>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)li.lds_bytes);
+                if (e != hipSuccess) return (int)e;
                 if (stats) hipLaunchKernelGGL((k_trace_bvh<true, true, 1024u>), grid, block, li.lds_bytes, stream, q);
                 else hipLaunchKernelGGL((k_trace_bvh<false, true, 1024u>), grid, block, li.lds_bytes, stream, q);
                 break;
@@ -995,6 +1012,21 @@ int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), dim3(256), 0, stream, ptris, slots, n, out);
     return (int)hipGetLastError();
+}
+
+int launch_deinterleave(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t padded_rows,
+                        uint32_t stripe_rows, uint32_t shard_count, void* stream_) {
+    if (width == 0 || height == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_deinterleave, dim3((width + 255u) / 256u, height), dim3(256), 0, stream, gathered, frame, width,
+                       height, padded_rows, stripe_rows, shard_count);
+    return (int)hipGetLastError();
+}
+
+size_t max_dynamic_lds(int device) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0) return 64u * 1024u;
+    return (size_t)v;
 }
 
 int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint32_t eb, uint32_t a_begin,

@@ -10,19 +10,28 @@
 // per-thread and the reference drives the iterator from a worker thread,
 // frame_buffer.rs:141-148) and reports failures as status + message instead of
 // panicking.
+//
+// Beyond the reference (one wgpu device, one synchronous pass per frame):
+//  * two frame slots (accumulation + RGBA8 each) so that the progressive iterator can run pass k+1
+//    while frame k is copied to the caller;
+//  * row-stripe sharding over several devices behind this same boundary -- one engine per device inside
+//    one process (rb_create_multi) or one process per device (rb_comm_init_rank) -- with ONE RCCL gather
+//    of the RGBA8 stripes to the root per delivered frame; rccl_gather.cpp.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <chrono>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "rb_internal.hpp"
+#include "rb_rccl.hpp"
 
 namespace {
 
@@ -46,12 +55,26 @@ struct DevBuf {
         if (e == hipSuccess) count = n;
         return e;
     }
+    // scratch that is sized per launch: keep an allocation that is large enough and not wastefully so
+    hipError_t reserve(size_t n) {
+        if (ptr && n <= count && count <= 4 * std::max<size_t>(n, 1)) return hipSuccess;
+        return resize(n);
+    }
+};
+
+// One frame: the accumulation (vec4<f32> per pixel: sum of radiance, sample count) and the packed RGBA8
+// image the kernels derive from it.  `done` is recorded after the launches that produced this slot.
+struct FrameSlot {
+    DevBuf<float> accum;
+    DevBuf<uint32_t> rgba;
+    hipEvent_t done = nullptr;
 };
 
 }  // namespace
 
 struct rb_engine {
     std::mutex mu;
+    mutable std::mutex err_mu;       // guards `error` for the const getters (rb_get_size, rb_last_error)
     mutable std::string error;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -63,6 +86,7 @@ struct rb_engine {
 
     bool initialized = false;        // GpuWrapper::initialized (gpu_wrapper.rs:69,117)
     bool have_uniforms = false;      // last update carried Create/Update uniforms (:303-329)
+    bool scene_valid = false;        // the buffers hold a scene that passed validate_scene (set by the last update)
     rb_uniforms uniforms{};          // as handed over (before count patch-up)
     rb_progressive prh{};            // gpu_wrapper.rs:19-53
     bool iter_initialized = false;   // RaytracerFrameIterator::initialized (lib.rs:131)
@@ -74,6 +98,7 @@ struct rb_engine {
     // Change of the last update for the three patched counts (gpu_wrapper.rs:475-495)
     uint32_t last_change_spheres = RB_KEEP, last_change_nodes = RB_KEEP, last_change_tris = RB_KEEP;
     bool prep_dirty = true;
+    uint32_t prep_tri_count = 0xFFFFFFFFu;  // uniforms.bvh_triangle_count (patched) the prepared triangles were made for
 
     DevBuf<rb_sphere> spheres;
     DevBuf<rb_point_light> lights;
@@ -87,20 +112,23 @@ struct rb_engine {
     DevBuf<uint32_t> tex_data;
     DevBuf<rb_texture_info> tex_info;
     DevBuf<float> srgb_lut;
-    DevBuf<float> accum;
-    DevBuf<uint32_t> out_rgba;
+    FrameSlot slot[2];               // slot[cur] holds the committed frame
+    int cur = 0;
+    bool spec_valid = false;         // slot[1 - cur] holds passes [spec_first, +spec_n) run ahead on top of slot[cur]
+    uint32_t spec_first = 0, spec_n = 0;
     DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> queue;
-    DevBuf<rb::SphereNode> fast_nodes; // opt-in fast triangle tree (RB_FLAG_FAST_BVH)
+    DevBuf<rb::SphereNode> fast_nodes; // the library's own triangle tree (walk mode "fast")
     DevBuf<rb::PrepTri> fast_tris;
     DevBuf<uint32_t> fast_slots, slot_meta, ref_parent, stack_overflow;
+    DevBuf<rb::FastCone> fast_cones;
     uint32_t fast_root = 0, fast_depth = 0;
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
     bool fast_ready = false;
     float fast_build_ms = 0.0f;
-    const char* fast_builder = "";  // which builder produced the fast tree ("host-sah" / "device-lbvh")
-    std::vector<rb_gpu_triangle> host_tris;  // kept only when RB_FLAG_FAST_BVH is set
+    const char* fast_builder = "";  // which builder produced the fast tree ("host-sah" / "device-ploc" / "device-lbvh")
+    std::vector<rb_gpu_triangle> host_tris;  // kept while the library's own tree may be (re)built
     std::vector<uint32_t> host_indices;
     DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
     DevBuf<float> sph_leaf;
@@ -119,17 +147,28 @@ struct rb_engine {
     uint32_t last_launches = 0;
     bool timing_pending = false;
     uint32_t max_mesh_index = 0;  // over the uploaded triangles
+
+    // ---- several devices behind one handle (rb_create_multi): this engine only coordinates; every part is a
+    // complete engine for one shard on one device.  Or one process per device (rb_comm_init_rank): this engine
+    // is shard `opt.shard_rank` and `net` holds its communicator.
+    std::vector<std::unique_ptr<rb_engine>> parts;
+    rb::Gather net;
 };
 
 namespace {
 
-int fail(rb_engine* e, int code, const char* fmt, ...) {
+int fail(const rb_engine* e, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (e) e->error = buf; else g_create_error = buf;
+    if (e) {
+        std::lock_guard<std::mutex> g(e->err_mu);
+        e->error = buf;
+    } else {
+        g_create_error = buf;
+    }
     return code;
 }
 
@@ -215,6 +254,8 @@ int validate(rb_engine* e, const rb_config* c) {
 
 // create_storage_buffer -- buffers.rs:232-249: an empty slice still allocates one
 // zero-filled element (wgpu zero-initialises), so arrayLength() is 1.
+// The copy is queued on the engine's stream from caller memory: every path that calls this ends in
+// update_locked's hipStreamSynchronize (or an earlier one) before the caller gets its buffers back.
 template <typename T>
 int upload(rb_engine* e, DevBuf<T>& buf, const void* src, size_t count, uint32_t* visible_len, bool pad_empty) {
     const size_t alloc = (count == 0 && pad_empty) ? 1 : count;
@@ -228,31 +269,44 @@ int upload(rb_engine* e, DevBuf<T>& buf, const void* src, size_t count, uint32_t
     return RB_OK;
 }
 
-// grow_resolution -- buffers.rs:171-180 (+ the stripe geometry of the sharded case)
-int resize_frame(rb_engine* e, uint32_t w, uint32_t h) {
-    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
-    const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
-    uint32_t local = h, padded = h;
+struct StripeGeometry {
+    uint32_t local = 0, padded = 0;
+};
+StripeGeometry stripe_geometry(const rb_options& opt, uint32_t h) {
+    const uint32_t sc = opt.shard_count > 1 ? opt.shard_count : 1;
+    const uint32_t sr = opt.stripe_rows ? opt.stripe_rows : rb::kDefaultStripeRows;
+    StripeGeometry g{h, h};
     if (sc > 1) {
         const uint32_t stripes = (h + sr - 1) / sr;
         const uint32_t per_rank = (stripes + sc - 1) / sc;  // equal on every rank (padded)
-        padded = per_rank * sr;
+        g.padded = per_rank * sr;
         uint32_t owned = 0;  // stripes this rank renders
-        for (uint32_t s = e->opt.shard_rank; s < stripes; s += sc) owned++;
-        local = owned * sr;  // the kernels additionally bound rows by global y < height
+        for (uint32_t s = opt.shard_rank; s < stripes; s += sc) owned++;
+        g.local = owned * sr;  // the kernels additionally bound rows by global y < height
     }
-    const uint64_t px = static_cast<uint64_t>(w) * padded;
+    return g;
+}
+
+// grow_resolution -- buffers.rs:171-180 (+ the stripe geometry of the sharded case)
+int resize_frame(rb_engine* e, uint32_t w, uint32_t h) {
+    const StripeGeometry g = stripe_geometry(e->opt, h);
+    const uint64_t px = static_cast<uint64_t>(w) * g.padded;
     if (px >= (1ull << 31)) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame of %u x %u pixels is too large", w, h);
-    HIP_TRY(e, e->accum.resize(px * 4));
-    HIP_TRY(e, e->out_rgba.resize(px));
+    e->spec_valid = false;
+    e->cur = 0;
+    e->slot[1].accum.release();   // the run-ahead slot is (re)allocated when the iterator first needs it
+    e->slot[1].rgba.release();
+    FrameSlot& s = e->slot[0];
+    HIP_TRY(e, s.accum.resize(px * 4));
+    HIP_TRY(e, s.rgba.resize(px));
     if (px) {
-        HIP_TRY(e, hipMemsetAsync(e->accum.ptr, 0, px * 16, e->stream));
-        HIP_TRY(e, hipMemsetAsync(e->out_rgba.ptr, 0, px * 4, e->stream));
+        HIP_TRY(e, hipMemsetAsync(s.accum.ptr, 0, px * 16, e->stream));
+        HIP_TRY(e, hipMemsetAsync(s.rgba.ptr, 0, px * 4, e->stream));
     }
     e->width = w;
     e->height = h;
-    e->local_rows = local;
-    e->padded_rows = padded;
+    e->local_rows = g.local;
+    e->padded_rows = g.padded;
     return RB_OK;
 }
 
@@ -263,8 +317,6 @@ int upload_textures(rb_engine* e, const rb_field& f) {
     uint32_t offset = 0;
     for (size_t i = 0; i < f.count; ++i) {  // process_textures, buffers.rs:151-168
         const size_t n = static_cast<size_t>(t[i].width) * t[i].height;
-        if (n > 0 && !t[i].rgba_data) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu has no data", i);
-        if (t[i].width == 0 || t[i].height == 0) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu is empty", i);
         info.push_back(rb_texture_info{offset, t[i].width, t[i].height, 0});
         data.insert(data.end(), t[i].rgba_data, t[i].rgba_data + n);
         offset += t[i].width * t[i].height;
@@ -311,19 +363,27 @@ int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
     return RB_OK;
 }
 
-// Applies one non-uniform field.  `first` = the engine's first update
+// What an update does with one non-uniform field.  `first` = the engine's first update
 // (gpu_wrapper.rs:117-163: only Create is acted on); otherwise :196-294.
-int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
+enum class Act { None, Take, Delete };
+Act field_action(int idx, const rb_field& f, bool first) {
     const bool bvh_field = (idx >= 5 && idx <= 7);
-    bool take = false, del = false;
-    if (first) {
-        take = (f.change == RB_CREATE);
-    } else {
-        if (f.change == RB_UPDATE) take = true;
-        else if (f.change == RB_DELETE) del = true;
-        else if (f.change == RB_CREATE) take = bvh_field;  // "Create not allowed after initialization" except BVH (:242-280)
-    }
-    if (!take && !del) return RB_OK;
+    if (first) return f.change == RB_CREATE ? Act::Take : Act::None;
+    if (f.change == RB_UPDATE) return Act::Take;
+    if (f.change == RB_DELETE) return Act::Delete;
+    if (f.change == RB_CREATE) return bvh_field ? Act::Take : Act::None;  // "Create not allowed after initialization" except BVH (:242-280)
+    return Act::None;
+}
+
+bool wants_own_tree(const rb_engine* e) {
+    if (e->opt.flags & RB_FLAG_REFERENCE_WALK) return false;
+    return rb::kFastWalkByDefault || (e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) != 0u;
+}
+
+int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
+    const Act act = field_action(idx, f, first);
+    if (act == Act::None) return RB_OK;
+    const bool del = act == Act::Delete;
     const void* src = del ? nullptr : f.ptr;
     const size_t n = del ? 0 : f.count;
     int rc = RB_OK;
@@ -355,13 +415,13 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
         case 6:
             rc = upload(e, e->indices, src, n, &e->n_indices, true);
             e->prep_dirty = true;
-            if (e->opt.flags & RB_FLAG_FAST_BVH) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
+            if (wants_own_tree(e)) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
             break;
         case 7:
             rc = upload(e, e->tris, src, n, nullptr, true);
             e->n_tris = static_cast<uint32_t>(n);
             e->prep_dirty = true;
-            if (e->opt.flags & RB_FLAG_FAST_BVH) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
+            if (wants_own_tree(e)) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
             break;
         case 8:
             if (del) { rb_field empty{RB_UPDATE, nullptr, 0}; rc = upload_textures(e, empty); }
@@ -372,55 +432,119 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
     return rc;
 }
 
-// Host-side checks that stand in for WGSL's robust buffer access: anything that
-// would make a HIP kernel read out of bounds or loop forever is refused here.
-int validate_scene(rb_engine* e, const rb_config* cfg) {
-    std::string why;
-    uint32_t depth = 0;
-    if (has_data(cfg->bvh_triangles)) {
+// Host-side checks that stand in for WGSL's robust buffer access: anything that would make a HIP kernel
+// read out of bounds or loop forever is refused.  They run on the scene the update WOULD produce -- the
+// incoming fields merged with the kept host copies -- before a single buffer is touched, so a refused
+// rb_update leaves the previous scene live and renderable.
+struct ScenePlan {
+    uint32_t bvh_stack = 0, max_mesh_index = 0;
+};
+int validate_scene(rb_engine* e, const rb_config* cfg, bool first, ScenePlan& plan) {
+    const Act a_nodes = field_action(5, cfg->bvh_nodes, first), a_idx = field_action(6, cfg->bvh_indices, first),
+              a_tris = field_action(7, cfg->bvh_triangles, first), a_meshes = field_action(3, cfg->meshes, first);
+    const bool take_uniforms = first ? (cfg->uniforms.change == RB_CREATE) : (cfg->uniforms.change == RB_UPDATE);
+    // ---- the tree the kernels would walk
+    const rb_bvh_node* nodes = e->host_nodes.data();
+    uint32_t n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+    if (a_nodes == Act::Take) {
+        nodes = static_cast<const rb_bvh_node*>(cfg->bvh_nodes.ptr);
+        if (cfg->bvh_nodes.count >= (1ull << 31)) return fail(e, RB_ERR_INVALID_BVH, "too many BVH nodes");
+        n_nodes = static_cast<uint32_t>(cfg->bvh_nodes.count);
+    } else if (a_nodes == Act::Delete) {
+        n_nodes = 0;
+    }
+    uint64_t index_len = e->n_indices;  // arrayLength(&bvh_indices): an empty vector still has one element
+    if (a_idx == Act::Take) index_len = std::max<uint64_t>(cfg->bvh_indices.count, 1);
+    else if (a_idx == Act::Delete) index_len = 1;
+    if (index_len >= (1ull << 31)) return fail(e, RB_ERR_INVALID_BVH, "too many BVH indices");
+    plan.bvh_stack = e->bvh_stack;
+    if (n_nodes > 0) {
+        std::string why;
+        uint32_t depth = 0;
+        if (!rb::bvh_validate(nodes, n_nodes, rb::kStackDepth, why, &depth)) return fail(e, RB_ERR_INVALID_BVH, "%s", why.c_str());
+        plan.bvh_stack = depth;
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const rb_bvh_node& n = nodes[i];
+            if (n.primitive_count > 0 && static_cast<uint64_t>(n.first_primitive) + n.primitive_count > index_len)
+                return fail(e, RB_ERR_INVALID_BVH, "leaf %u covers [%u, +%u) of %llu bvh_indices", i, n.first_primitive,
+                            n.primitive_count, static_cast<unsigned long long>(index_len));
+        }
+    }
+    // ---- every triangle's material must exist (shader.wgsl:370 reads meshes[tri.mesh_index])
+    uint64_t n_tris = e->n_tris;
+    plan.max_mesh_index = e->max_mesh_index;
+    if (a_tris == Act::Take) {
         const rb_gpu_triangle* t = static_cast<const rb_gpu_triangle*>(cfg->bvh_triangles.ptr);
         uint32_t mx = 0;
         for (size_t i = 0; i < cfg->bvh_triangles.count; ++i) mx = std::max(mx, t[i].mesh_index);
-        e->max_mesh_index = mx;
+        plan.max_mesh_index = mx;
+        n_tris = cfg->bvh_triangles.count;
+        if (n_tris >= (1ull << 31)) return fail(e, RB_ERR_INVALID_BVH, "too many triangles");
+    } else if (a_tris == Act::Delete) {
+        n_tris = 0;
+        plan.max_mesh_index = 0;
     }
-    const uint32_t n_nodes = static_cast<uint32_t>(e->host_nodes.size());
-    if (n_nodes > 0) {
-        if (!rb::bvh_validate(e->host_nodes.data(), n_nodes, rb::kStackDepth, why, &depth))
-            return fail(e, RB_ERR_INVALID_BVH, "%s", why.c_str());
-        e->bvh_stack = depth;
-        for (uint32_t i = 0; i < n_nodes; ++i) {
-            const rb_bvh_node& n = e->host_nodes[i];
-            if (n.primitive_count > 0 &&
-                static_cast<uint64_t>(n.first_primitive) + n.primitive_count > e->n_indices)
-                return fail(e, RB_ERR_INVALID_BVH, "leaf %u covers [%u, +%u) of %u bvh_indices", i, n.first_primitive,
-                            n.primitive_count, e->n_indices);
+    uint64_t n_meshes = e->n_meshes;
+    if (a_meshes == Act::Take) n_meshes = cfg->meshes.count;
+    const uint32_t color_hash = take_uniforms ? static_cast<const rb_uniforms*>(cfg->uniforms.ptr)->color_hash_enabled
+                                              : e->uniforms.color_hash_enabled;
+    if (n_tris > 0 && color_hash == 0 && plan.max_mesh_index >= n_meshes)
+        return fail(e, RB_ERR_INVALID_MESHES, "a triangle references mesh %u of %llu", plan.max_mesh_index,
+                    static_cast<unsigned long long>(n_meshes));
+    // ---- textures and the frame
+    if (field_action(8, cfg->textures, first) == Act::Take) {
+        const rb_texture* t = static_cast<const rb_texture*>(cfg->textures.ptr);
+        for (size_t i = 0; i < cfg->textures.count; ++i) {
+            if (t[i].width == 0 || t[i].height == 0) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu is empty", i);
+            if (!t[i].rgba_data) return fail(e, RB_ERR_INVALID_TEXTURES, "texture %zu has no data", i);
         }
     }
-    if (e->n_tris > 0 && e->uniforms.color_hash_enabled == 0 && e->max_mesh_index >= e->n_meshes)
-        return fail(e, RB_ERR_INVALID_MESHES, "a triangle references mesh %u of %u", e->max_mesh_index, e->n_meshes);
+    if (take_uniforms) {
+        const rb_uniforms* u = static_cast<const rb_uniforms*>(cfg->uniforms.ptr);
+        const uint64_t px = static_cast<uint64_t>(u->width) * stripe_geometry(e->opt, u->height).padded;
+        if (px >= (1ull << 31)) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame of %u x %u pixels is too large", u->width, u->height);
+    }
     return RB_OK;
 }
 
-void set_device(rb_engine* e) { (void)hipSetDevice(e->device); }
+void set_device(const rb_engine* e) { (void)hipSetDevice(e->device); }
+
+// update_uniforms count patch-up -- gpu_wrapper.rs:475-495: Create/Update overwrite the count with the
+// vector length, Delete zeroes it, Keep leaves the caller's value (clamped to the buffer here so that a
+// stale count cannot read out of bounds; the WGSL relies on robust buffer access for that).
+uint32_t patch_count(uint32_t change, uint32_t given, uint32_t len) {
+    if (change == RB_CREATE || change == RB_UPDATE) return len;
+    if (change == RB_DELETE) return 0u;
+    return std::min(given, len);
+}
 
 int ensure_prepared(rb_engine* e) {
-    if (!e->prep_dirty) return RB_OK;
+    // shader.wgsl:336 skips triangle ids >= uniforms.bvh_triangle_count: the prepared triangles carry that
+    // guard as their `valid` word, so they depend on the (patched) count as well as on the buffers
+    const uint32_t tri_count = patch_count(e->last_change_tris, e->uniforms.bvh_triangle_count, e->n_tris);
+    if (!e->prep_dirty && e->prep_tri_count == tri_count) return RB_OK;
     const uint32_t len = e->n_indices;  // arrayLength(&bvh_indices) >= 1
     HIP_TRY(e, e->ptris.resize(len));
     HIP_TRY(e, e->pshade.resize(len));
-    int rc = rb::launch_prep_tris(e->tris.ptr, e->n_tris, e->indices.ptr, len, e->ptris.ptr, e->pshade.ptr, e->stream);
+    int rc = rb::launch_prep_tris(e->tris.ptr, tri_count, e->indices.ptr, len, e->ptris.ptr, e->pshade.ptr, e->stream);
     if (rc) return fail(e, RB_ERR_DEVICE, "prep kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     e->prep_dirty = false;
-    // ---- opt-in fast tree over the same triangles
+    e->prep_tri_count = tri_count;
+    // ---- the library's own tree over the same triangles (default for multi-node meshes)
     e->fast_ready = false;
-    if ((e->opt.flags & RB_FLAG_FAST_BVH) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty()) {
+    if (wants_own_tree(e) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
         rb::FastTree ft;
         const auto t_begin = std::chrono::steady_clock::now();
-        const uint32_t n_tris = static_cast<uint32_t>(e->host_tris.size()), n_idx = static_cast<uint32_t>(e->host_indices.size());
+        const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size());
         const uint32_t n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+        const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
         bool built = false;
         e->fast_builder = "";
-        if (e->opt.flags & RB_FLAG_DEVICE_BVH) {
+        // which builder: the device one from kDeviceBuildMinTriangles up (milliseconds instead of ~0.15 s per
+        // million triangles), the host's binned SAH below; either can be forced
+        const bool force_host = (e->opt.flags & RB_FLAG_HOST_BVH) != 0u, force_dev = (e->opt.flags & RB_FLAG_DEVICE_BVH) != 0u;
+        const bool try_device = !force_host && (force_dev || n_tris >= rb::kDeviceBuildMinTriangles);
+        if (try_device) {
             // reference-order metadata on the host (one pass over the caller's tree), the tree on the device
             if (rb::fast_bvh_prepare(n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft) &&
                 ft.slots.size() >= 1024) {
@@ -429,10 +553,11 @@ int ensure_prepared(rb_engine* e) {
                 rc = upload(e, visit_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
                 if (rc) return rc;
                 HIP_TRY(e, e->fast_nodes.resize(n - 1));
+                HIP_TRY(e, e->fast_cones.resize(n - 1));
                 HIP_TRY(e, e->fast_slots.resize(n));
                 rb::DeviceTreeInfo info{};
                 rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
-                                               e->fast_slots.ptr, &info, e->stream,
+                                               e->fast_cones.ptr, e->fast_slots.ptr, &info, e->stream,
                                                (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
                 if (rc && rc != static_cast<int>(hipErrorNotReady))
                     return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
@@ -463,8 +588,9 @@ int ensure_prepared(rb_engine* e) {
         if (!built) {
             if (!rb::fast_bvh_build(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes,
                                     rb::kStackDepth, ft))
-                return RB_OK;  // keep the exact walk
+                return RB_OK;  // keep the reference walk
             rc = upload(e, e->fast_nodes, ft.nodes.data(), ft.nodes.size(), nullptr, true);
+            if (!rc) rc = upload(e, e->fast_cones, ft.cones.data(), ft.cones.size(), nullptr, true);
             if (!rc) rc = upload(e, e->fast_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
             if (rc) return rc;
             e->fast_builder = "host-sah";
@@ -491,19 +617,12 @@ int ensure_prepared(rb_engine* e) {
     return RB_OK;
 }
 
-rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
+rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int dst) {
     rb::KParams p{};
     p.u = e->uniforms;
-    // update_uniforms count patch-up -- gpu_wrapper.rs:475-495.  Keep leaves the caller's
-    // value; it is clamped to the buffer so a stale count cannot read out of bounds.
-    auto patch = [](uint32_t change, uint32_t given, uint32_t len) -> uint32_t {
-        if (change == RB_CREATE || change == RB_UPDATE) return len;
-        if (change == RB_DELETE) return 0u;
-        return std::min(given, len);
-    };
-    p.u.spheres_count = patch(e->last_change_spheres, e->uniforms.spheres_count, e->n_spheres);
-    p.u.bvh_node_count = patch(e->last_change_nodes, e->uniforms.bvh_node_count, e->n_nodes);
-    p.u.bvh_triangle_count = patch(e->last_change_tris, e->uniforms.bvh_triangle_count, e->n_tris);
+    p.u.spheres_count = patch_count(e->last_change_spheres, e->uniforms.spheres_count, e->n_spheres);
+    p.u.bvh_node_count = patch_count(e->last_change_nodes, e->uniforms.bvh_node_count, e->n_nodes);
+    p.u.bvh_triangle_count = patch_count(e->last_change_tris, e->uniforms.bvh_triangle_count, e->n_tris);
     p.spheres = e->spheres.ptr;
     p.lights = e->lights.ptr;
     p.meshes = e->meshes.ptr;
@@ -516,8 +635,9 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.tex_data = e->tex_data.ptr;
     p.tex_info = e->tex_info.ptr;
     p.srgb_lut = e->srgb_lut.ptr;
-    p.accum = e->accum.ptr;
-    p.out_rgba = e->out_rgba.ptr;
+    p.accum_in = e->slot[src].accum.ptr;
+    p.accum_out = e->slot[dst].accum.ptr;
+    p.out_rgba = e->slot[dst].rgba.ptr;
     p.counters = e->counters.ptr;
     p.queue = e->queue.ptr;
     p.n_lights = e->n_lights;
@@ -535,6 +655,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     p.colors = e->colors.ptr;
     const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
+    p.fast_cones = e->fast_cones.ptr;
     p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
     p.fast_slots = e->fast_slots.ptr;
     p.slot_meta = e->slot_meta.ptr;
@@ -569,84 +690,15 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
 
 int require_ready(rb_engine* e) {
     if (!e->initialized) return fail(e, RB_ERR_NOT_INITIALIZED, "engine has not received its first update");
+    if (!e->scene_valid) return fail(e, RB_ERR_DEVICE, "the last update failed half-way on the device; send the scene again");
     if (!e->have_uniforms) return fail(e, RB_ERR_UNIFORMS_NOT_INITIALIZED, "Uniforms must be initialized");
     return RB_OK;
 }
 
 int clear_accum(rb_engine* e) {
     const size_t px = static_cast<size_t>(e->width) * e->padded_rows;
-    if (px) HIP_TRY(e, hipMemsetAsync(e->accum.ptr, 0, px * 16, e->stream));
-    return RB_OK;
-}
-
-// dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400.
-// The bvh_node_count patched for Keep is only known after make_params.
-int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
-    int rc = ensure_prepared(e);
-    if (rc) return rc;
-    if (n_passes == 0 || e->width == 0 || e->local_rows == 0) return RB_OK;
-    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
-    const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
-    uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
-    if (kernel == RB_KERNEL_STREAM) {
-        // One float4 per (pixel, sample) of a launch chunk.  Keep the item count below 2^31
-        // and, unless the caller fixed the chunk, the buffer within a budget (default 40 GiB of the
-        // 288 GB of HBM: the whole C2 frame -- 1024 spp, 34 GB -- is then one launch; 32 / 8 / 2 / 1
-        // launches per frame measured 23.5 / 24.6 / 24.7 / 24.7 G segments/s).
-        const uint64_t tiles = static_cast<uint64_t>((e->width + 7) / 8) * ((e->local_rows + 7) / 8);
-        const uint64_t per_pass = tiles * 64ull * e->prh.samples_per_pass;  // items per pass
-        const uint64_t budget_items = (e->opt._reserved[1] ? static_cast<uint64_t>(e->opt._reserved[1]) : 40960ull) * (1ull << 20) / 16ull;
-        uint64_t max_chunk = std::min<uint64_t>((1ull << 31) / std::max<uint64_t>(per_pass, 1) , 0xFFFFFFFFull);
-        if (!e->opt.passes_per_launch) max_chunk = std::min(max_chunk, std::max<uint64_t>(budget_items / std::max<uint64_t>(per_pass, 1), 1));
-        if (max_chunk == 0) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame too large for one launch");
-        chunk = static_cast<uint32_t>(std::min<uint64_t>(chunk, max_chunk));
-        HIP_TRY(e, e->colors.resize(per_pass * chunk * 4));
-    }
-    HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
-    uint32_t launches = 0;
-    e->ev_used = 0;
-    for (uint32_t done = 0; done < n_passes;) {
-        const uint32_t n = std::min(chunk, n_passes - done);
-        rb::KParams p = make_params(e, first_pass + done, n);
-        rb::LaunchInfo li{};
-        // per-chunk timing events (first 256 chunks of a group; later ones only count in the total)
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        if (e->ev_used + 3 <= 768) {
-            while (e->ev_pool.size() < e->ev_used + 3) {
-                hipEvent_t x;
-                HIP_TRY(e, hipEventCreate(&x));
-                e->ev_pool.push_back(x);
-            }
-            for (int i = 0; i < 3; ++i) ev[i] = e->ev_pool[e->ev_used + i];
-            e->ev_used += 3;
-            HIP_TRY(e, hipEventRecord(ev[0], e->stream));
-        }
-        rc = rb::launch_render(p, kernel, stats, e->stream, &li, ev[1]);
-        if (rc) return fail(e, RB_ERR_DEVICE, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
-        if (ev[2]) {
-            if (kernel != RB_KERNEL_STREAM) HIP_TRY(e, hipEventRecord(ev[1], e->stream));
-            HIP_TRY(e, hipEventRecord(ev[2], e->stream));
-        }
-        if (li.kernel_name) e->last_kernel_name = li.kernel_name;
-        done += n;
-        launches++;
-    }
-    HIP_TRY(e, hipEventRecord(e->ev_end, e->stream));
-    e->last_launches = launches;
-    e->timing_pending = true;
-    e->stats.launches += launches;
-    return RB_OK;
-}
-
-int read_rgba(rb_engine* e, uint8_t* out) {
-    if (!out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
-    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
-    const size_t row_bytes = static_cast<size_t>(e->width) * 4;
-    // The destination is caller-owned, normally pageable memory: finish the stream's work, then a
-    // blocking copy.  (An async copy into pageable memory followed by a stream wait leaves it to the
-    // runtime when the bytes reach the caller's buffer.)
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(out, e->out_rgba.ptr, row_bytes * (sc == 1 ? e->height : e->padded_rows), hipMemcpyDeviceToHost));
+    e->spec_valid = false;
+    if (px) HIP_TRY(e, hipMemsetAsync(e->slot[e->cur].accum.ptr, 0, px * 16, e->stream));
     return RB_OK;
 }
 
@@ -671,18 +723,129 @@ int accumulate_timing(rb_engine* e) {
     return RB_OK;
 }
 
+// Colour-buffer budget of the stream kernels (one float4 per (pixel, sample) of a launch chunk): the caller's
+// figure, else 4 GiB but never more than half of what the device has free right now -- eight launches per C2
+// frame instead of one cost 0.4 %, and a library that sits behind a GUI should not take 34 GB for a 1080p frame.
+uint64_t color_budget_bytes(const rb_engine* e) {
+    if (e->opt._reserved[1]) return static_cast<uint64_t>(e->opt._reserved[1]) << 20;
+    uint64_t budget = 4ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, (free_b + e->colors.count * sizeof(float)) / 2);
+    return std::max<uint64_t>(budget, 1ull << 20);
+}
+
+// dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400: passes
+// [first_pass, first_pass + n_passes) on top of slot `src`, into slot `dst` (the same slot, or the other one
+// when the iterator runs a pass ahead).
+int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int dst) {
+    int rc = ensure_prepared(e);
+    if (rc) return rc;
+    if (n_passes == 0 || e->width == 0 || e->local_rows == 0) {
+        e->last_launches = 0;
+        return RB_OK;
+    }
+    if (e->timing_pending) {  // fold the previous group's events before they are recorded again
+        rc = accumulate_timing(e);
+        if (rc) return rc;
+    }
+    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
+    const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
+    uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
+    if (kernel == RB_KERNEL_STREAM) {
+        // One float4 per (pixel, sample) of a launch chunk.  Keep the item count below 2^31 and, unless the
+        // caller fixed the chunk, the buffer within the budget; if the device cannot give even that, halve.
+        const uint64_t tiles = static_cast<uint64_t>((e->width + 7) / 8) * ((e->local_rows + 7) / 8);
+        const uint64_t per_pass = tiles * 64ull * e->prh.samples_per_pass;  // items per pass
+        const uint64_t budget_items = color_budget_bytes(e) / 16ull;
+        uint64_t max_chunk = std::min<uint64_t>((1ull << 31) / std::max<uint64_t>(per_pass, 1) , 0xFFFFFFFFull);
+        if (!e->opt.passes_per_launch) max_chunk = std::min(max_chunk, std::max<uint64_t>(budget_items / std::max<uint64_t>(per_pass, 1), 1));
+        if (max_chunk == 0) return fail(e, RB_ERR_INVALID_UNIFORMS, "frame too large for one launch");
+        chunk = static_cast<uint32_t>(std::min<uint64_t>(chunk, max_chunk));
+        for (;;) {
+            const hipError_t st = e->colors.reserve(per_pass * chunk * 4);
+            if (st == hipSuccess) break;
+            (void)hipGetLastError();  // clear the sticky out-of-memory status
+            if (st != hipErrorOutOfMemory || chunk == 1)
+                return fail(e, RB_ERR_DEVICE, "colour buffer of %llu bytes: %s", static_cast<unsigned long long>(per_pass * chunk * 16ull),
+                            hipGetErrorString(st));
+            chunk = (chunk + 1) / 2;
+        }
+    }
+    HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
+    uint32_t launches = 0;
+    e->ev_used = 0;
+    for (uint32_t done = 0; done < n_passes;) {
+        const uint32_t n = std::min(chunk, n_passes - done);
+        // the first chunk resumes `src`; later chunks of the same group continue in `dst`
+        rb::KParams p = make_params(e, first_pass + done, n, done == 0 ? src : dst, dst);
+        rb::LaunchInfo li{};
+        // per-chunk timing events (first 256 chunks of a group; later ones only count in the total)
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        if (e->ev_used + 3 <= 768) {
+            while (e->ev_pool.size() < e->ev_used + 3) {
+                hipEvent_t x;
+                HIP_TRY(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
+            for (int i = 0; i < 3; ++i) ev[i] = e->ev_pool[e->ev_used + i];
+            e->ev_used += 3;
+            HIP_TRY(e, hipEventRecord(ev[0], e->stream));
+        }
+        rc = rb::launch_render(p, kernel, stats, e->stream, &li, ev[1]);
+        if (rc) return fail(e, RB_ERR_DEVICE, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (ev[2]) {
+            if (kernel != RB_KERNEL_STREAM) HIP_TRY(e, hipEventRecord(ev[1], e->stream));
+            HIP_TRY(e, hipEventRecord(ev[2], e->stream));
+        }
+        if (li.kernel_name) e->last_kernel_name = li.kernel_name;
+        done += n;
+        launches++;
+    }
+    HIP_TRY(e, hipEventRecord(e->ev_end, e->stream));
+    HIP_TRY(e, hipEventRecord(e->slot[dst].done, e->stream));
+    e->last_launches = launches;
+    e->timing_pending = true;
+    e->stats.launches += launches;
+    return RB_OK;
+}
+
+// Copies the committed frame's RGBA8 rows (local stripe order when sharded) to caller memory: the host waits
+// for the launches that produced the slot, then a blocking copy.  The engine's stream is non-blocking, so a
+// pass the iterator has already started on the OTHER slot keeps running underneath this copy.
+int read_slot_rgba(rb_engine* e, int slot, uint8_t* out) {
+    if (!out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    const size_t bytes = static_cast<size_t>(e->width) * 4 * (sc == 1 ? e->height : e->padded_rows);
+    if (bytes == 0) return RB_OK;
+    HIP_TRY(e, hipEventSynchronize(e->slot[slot].done));
+    HIP_TRY(e, hipMemcpy(out, e->slot[slot].rgba.ptr, bytes, hipMemcpyDeviceToHost));
+    return RB_OK;
+}
+
+int read_rgba(rb_engine* e, uint8_t* out) {
+    // uploads and clears queued after the slot's last launch group must be over as well
+    HIP_TRY(e, hipEventRecord(e->slot[e->cur].done, e->stream));
+    return read_slot_rgba(e, e->cur, out);
+}
+
 int update_fields(rb_engine* e, const rb_config* cfg) {
     int rc = check_fields(e, cfg);
     if (rc) return rc;
     const bool first = !e->initialized;
     rc = first ? validate_init(e, cfg) : validate(e, cfg);
     if (rc) return rc;
+    ScenePlan plan;
+    rc = validate_scene(e, cfg, first, plan);
+    if (rc) return rc;   // nothing has been touched: the previous scene stays live
 
-    // ---- uniforms (gpu_wrapper.rs:122-136 / :165-192)
+    // ---- from here on the buffers change; a device failure half-way leaves the engine refusing to render
+    e->scene_valid = false;
+    e->spec_valid = false;
+    // uniforms (gpu_wrapper.rs:122-136 / :165-192)
     const bool take_uniforms = first ? (cfg->uniforms.change == RB_CREATE) : (cfg->uniforms.change == RB_UPDATE);
     if (take_uniforms) {
         const rb_uniforms* u = static_cast<const rb_uniforms*>(cfg->uniforms.ptr);
-        if (u->width != e->width || u->height != e->height || e->accum.ptr == nullptr) {
+        if (u->width != e->width || u->height != e->height || e->slot[0].accum.ptr == nullptr) {
             rc = resize_frame(e, u->width, u->height);
             if (rc) return rc;
         }
@@ -701,9 +864,10 @@ int update_fields(rb_engine* e, const rb_config* cfg) {
     e->last_change_spheres = cfg->spheres.change;
     e->last_change_nodes = cfg->bvh_nodes.change;
     e->last_change_tris = cfg->bvh_triangles.change;
-    rc = validate_scene(e, cfg);
-    if (rc) return rc;
+    e->bvh_stack = plan.bvh_stack;
+    e->max_mesh_index = plan.max_mesh_index;
     e->initialized = true;
+    e->scene_valid = true;
     return RB_OK;
 }
 
@@ -719,30 +883,90 @@ int update_locked(rb_engine* e, const rb_config* cfg) {
     return RB_OK;
 }
 
-int render_locked(rb_engine* e, uint8_t* rgba_out) {
+// zero the accumulation, run every pass (dispatch_compute, gpu_wrapper.rs:406-426) -- no read-back
+int render_async(rb_engine* e) {
     int rc = require_ready(e);
     if (rc) return rc;
-    if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
-    rc = clear_accum(e);  // dispatch_compute, gpu_wrapper.rs:407-411
+    rc = clear_accum(e);  // :407-411
     if (rc) return rc;
     e->prh.current_pass = 0;
-    rc = dispatch(e, 0, e->prh.total_passes);
+    rc = dispatch(e, 0, e->prh.total_passes, e->cur, e->cur);
     if (rc) return rc;
     e->prh.current_pass = e->prh.total_passes ? e->prh.total_passes - 1 : 0;  // loop variable's last value (:415)
-    rc = read_rgba(e, rgba_out);
+    return RB_OK;
+}
+
+int render_locked(rb_engine* e, uint8_t* rgba_out) {
+    if (!rgba_out && !(e->net.nranks > 1 && e->net.rank != 0)) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    int rc = render_async(e);
     if (rc) return rc;
+    if (e->net.nranks > 1) {  // one process per device: the frame is assembled on rank 0
+        std::string why;
+        if (rb::gather_process(e->net, e->slot[e->cur].rgba.ptr, e->width, e->height, e->padded_rows,
+                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->stream, rgba_out, why))
+            return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
+    } else {
+        rc = read_rgba(e, rgba_out);
+        if (rc) return rc;
+    }
     return accumulate_timing(e);
 }
 
-rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
-    g_create_error.clear();
-    if (!cfg) { fail(nullptr, RB_ERR_NULL_ARGUMENT, "config is NULL"); return nullptr; }
-    if (check_fields(nullptr, cfg)) return nullptr;
-    // GpuBuffers::new panics unless these are Create (buffers.rs:74-97)
-    if (validate_init(nullptr, cfg)) return nullptr;
-    rb_options opt{};
-    opt.device = -1;
-    if (opt_in) opt = *opt_in;
+// One delivered frame of the progressive iterator: passes [current_pass, +n).  The frame is taken from the
+// run-ahead slot when the previous call started exactly these passes there (and nothing has touched the
+// scene or the accumulation since); the next group is started on the other slot BEFORE this frame is
+// copied out, so compute and read-back overlap (frame_buffer.rs:164-221 pumps frames from a worker thread;
+// lib.rs:200-205 syncs, maps and mirrors per pass).
+int iter_next_locked(rb_engine* e, uint8_t* rgba_out) {
+    if (!(e->prh.current_pass < e->prh.total_passes))
+        return fail(e, RB_ERR_NO_MORE_FRAMES, "No more frames available");  // lib.rs:170-177
+    int rc = require_ready(e);
+    if (rc) return rc;
+    const bool multiproc = e->net.nranks > 1;
+    if (!rgba_out && !(multiproc && e->net.rank != 0)) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    if (!e->iter_initialized) {  // lib.rs:181-192
+        rc = clear_accum(e);
+        if (rc) return rc;
+        e->iter_initialized = true;
+    }
+    const uint32_t per = std::max(e->iter_passes_per_frame, 1u);
+    const uint32_t n = std::min(per, e->prh.total_passes - e->prh.current_pass);
+    if (e->spec_valid && e->spec_first == e->prh.current_pass && e->spec_n == n) {
+        e->cur = 1 - e->cur;   // commit the pass group that has been running since the previous call
+        e->spec_valid = false;
+    } else {
+        e->spec_valid = false;
+        rc = dispatch(e, e->prh.current_pass, n, e->cur, e->cur);  // lib.rs:200-203 (n = 1 there)
+        if (rc) return rc;
+    }
+    e->prh.current_pass += n;  // lib.rs:213
+    rc = accumulate_timing(e);
+    if (rc) return rc;
+    // ---- run ahead: the next group on the other slot
+    const bool run_ahead = !multiproc && !(e->opt.flags & RB_FLAG_NO_RUN_AHEAD) && e->prh.current_pass < e->prh.total_passes;
+    if (run_ahead) {
+        FrameSlot& o = e->slot[1 - e->cur];
+        const size_t px = static_cast<size_t>(e->width) * e->padded_rows;
+        HIP_TRY(e, o.accum.resize(px * 4));
+        HIP_TRY(e, o.rgba.resize(px));
+        const uint32_t n2 = std::min(per, e->prh.total_passes - e->prh.current_pass);
+        rc = dispatch(e, e->prh.current_pass, n2, e->cur, 1 - e->cur);
+        if (rc) return rc;
+        e->spec_valid = true;
+        e->spec_first = e->prh.current_pass;
+        e->spec_n = n2;
+    }
+    if (multiproc) {
+        std::string why;
+        if (rb::gather_process(e->net, e->slot[e->cur].rgba.ptr, e->width, e->height, e->padded_rows,
+                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->stream, rgba_out, why))
+            return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
+        return RB_OK;
+    }
+    return read_slot_rgba(e, e->cur, rgba_out);  // lib.rs:205
+}
+
+rb_engine* create_single(const rb_config* cfg, const rb_options& opt) {
     if (opt.shard_count > 1 && opt.shard_rank >= opt.shard_count) {
         fail(nullptr, RB_ERR_INVALID_OPTIONS, "shard_rank %u >= shard_count %u", opt.shard_rank, opt.shard_count);
         return nullptr;
@@ -758,13 +982,15 @@ rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
     e->opt = opt;
     auto bail = [&](const char* what, hipError_t st) -> rb_engine* {
         fail(nullptr, RB_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(st));
-        delete e;
+        rb_destroy(e);
         return nullptr;
     };
     hipError_t st;
     if ((st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", st);
     if ((st = hipEventCreate(&e->ev_begin)) != hipSuccess) return bail("hipEventCreate", st);
     if ((st = hipEventCreate(&e->ev_end)) != hipSuccess) return bail("hipEventCreate", st);
+    for (FrameSlot& s : e->slot)
+        if ((st = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", st);
     if ((st = e->counters.resize(rb::C_COUNT)) != hipSuccess) return bail("hipMalloc(counters)", st);
     if ((st = e->queue.resize(4)) != hipSuccess) return bail("hipMalloc(queue)", st);
     if ((st = hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream)) != hipSuccess)
@@ -783,6 +1009,96 @@ rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
     return e;
 }
 
+bool check_create(const rb_config* cfg) {
+    g_create_error.clear();
+    if (!cfg) { fail(nullptr, RB_ERR_NULL_ARGUMENT, "config is NULL"); return false; }
+    if (check_fields(nullptr, cfg)) return false;
+    // GpuBuffers::new panics unless these are Create (buffers.rs:74-97)
+    if (validate_init(nullptr, cfg)) return false;
+    return true;
+}
+
+rb_engine* create_impl(const rb_config* cfg, const rb_options* opt_in) {
+    if (!check_create(cfg)) return nullptr;
+    rb_options opt{};
+    opt.device = -1;
+    if (opt_in) opt = *opt_in;
+    return create_single(cfg, opt);
+}
+
+// ------------------------------------------------------------------ several devices, one handle ----
+bool is_group(const rb_engine* e) { return !e->parts.empty(); }
+
+void copy_error(rb_engine* g, const rb_engine* part) {
+    std::string msg;
+    {
+        std::lock_guard<std::mutex> l(part->err_mu);
+        msg = part->error;
+    }
+    std::lock_guard<std::mutex> l(g->err_mu);
+    g->error = "device " + std::to_string(part->device) + ": " + msg;
+}
+
+#define PART_TRY(g, part, call)            \
+    do {                                   \
+        set_device(part);                  \
+        const int _rc = (call);            \
+        if (_rc) {                         \
+            copy_error((g), (part));       \
+            return _rc;                    \
+        }                                  \
+    } while (0)
+
+int group_update(rb_engine* g, const rb_config* cfg) {
+    for (auto& p : g->parts) PART_TRY(g, p.get(), update_locked(p.get(), cfg));
+    rb_engine* p0 = g->parts[0].get();
+    g->width = p0->width;
+    g->height = p0->height;
+    g->have_uniforms = p0->have_uniforms;
+    g->initialized = p0->initialized;
+    g->prh = p0->prh;
+    return RB_OK;
+}
+
+// the one exchange step: every part's RGBA8 stripes to the root device, de-interleaved there, then read back
+int group_deliver(rb_engine* g, uint8_t* rgba_out) {
+    std::vector<rb::GatherSource> src;
+    for (auto& p : g->parts) src.push_back(rb::GatherSource{p->device, p->stream, p->slot[p->cur].rgba.ptr});
+    rb_engine* p0 = g->parts[0].get();
+    const uint32_t sr = p0->opt.stripe_rows ? p0->opt.stripe_rows : rb::kDefaultStripeRows;
+    std::string why;
+    if (rb::gather_group(g->net, src, p0->width, p0->height, p0->padded_rows, sr, rgba_out, why))
+        return fail(g, RB_ERR_DEVICE, "%s", why.c_str());
+    for (auto& p : g->parts) PART_TRY(g, p.get(), accumulate_timing(p.get()));
+    return RB_OK;
+}
+
+int group_render(rb_engine* g, uint8_t* rgba_out) {
+    if (!rgba_out) return fail(g, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    for (auto& p : g->parts) PART_TRY(g, p.get(), render_async(p.get()));  // all devices render concurrently
+    g->prh = g->parts[0]->prh;
+    return group_deliver(g, rgba_out);
+}
+
+int group_iter_next(rb_engine* g, uint8_t* rgba_out) {
+    rb_engine* p0 = g->parts[0].get();
+    if (!(p0->prh.current_pass < p0->prh.total_passes)) return fail(g, RB_ERR_NO_MORE_FRAMES, "No more frames available");
+    if (!rgba_out) return fail(g, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    for (auto& pp : g->parts) {
+        rb_engine* p = pp.get();
+        PART_TRY(g, p, require_ready(p));
+        if (!p->iter_initialized) {
+            PART_TRY(g, p, clear_accum(p));
+            p->iter_initialized = true;
+        }
+        const uint32_t n = std::min(std::max(g->iter_passes_per_frame, 1u), p->prh.total_passes - p->prh.current_pass);
+        PART_TRY(g, p, dispatch(p, p->prh.current_pass, n, p->cur, p->cur));
+        p->prh.current_pass += n;
+    }
+    g->prh = p0->prh;
+    return group_deliver(g, rgba_out);
+}
+
 }  // namespace
 
 // ============================================================== C ABI ======
@@ -791,22 +1107,106 @@ extern "C" {
 rb_engine* rb_create(const rb_config* cfg) { return create_impl(cfg, nullptr); }
 rb_engine* rb_create_ex(const rb_config* cfg, const rb_options* opt) { return create_impl(cfg, opt); }
 
+rb_engine* rb_create_multi(const rb_config* cfg, const rb_options* opt_in, const int32_t* devices, uint32_t n_devices) {
+    if (!check_create(cfg)) return nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) {
+        fail(nullptr, RB_ERR_INVALID_OPTIONS, "rb_create_multi needs 1..64 devices");
+        return nullptr;
+    }
+    rb_options opt{};
+    if (opt_in) opt = *opt_in;
+    if (opt.shard_count > 1) {
+        fail(nullptr, RB_ERR_INVALID_OPTIONS, "rb_create_multi shards by itself: leave shard_rank / shard_count zero");
+        return nullptr;
+    }
+    std::unique_ptr<rb_engine> g(new rb_engine());
+    g->opt = opt;
+    g->device = devices[0];
+    for (uint32_t r = 0; r < n_devices; ++r) {
+        rb_options po = opt;
+        po.device = devices[r];
+        po.shard_rank = r;
+        po.shard_count = n_devices;
+        rb_engine* p = create_single(cfg, po);
+        if (!p) {   // g_create_error is set
+            rb_destroy(g.release());
+            return nullptr;
+        }
+        g->parts.emplace_back(p);
+    }
+    std::vector<int> devs(devices, devices + n_devices);
+    std::string why;
+    if (rb::gather_init_group(g->net, devs, (opt.flags & RB_FLAG_GATHER_PEER_COPY) != 0u, why)) {
+        rb_destroy(g.release());
+        fail(nullptr, RB_ERR_DEVICE, "%s", why.c_str());
+        return nullptr;
+    }
+    rb_engine* out = g.release();
+    return out;
+}
+
+int rb_comm_unique_id(uint8_t id_out[RB_COMM_ID_BYTES]) {
+    if (!id_out) return RB_ERR_NULL_ARGUMENT;
+    std::string why;
+    if (rb::gather_unique_id(id_out, why)) {
+        g_create_error = why;
+        return RB_ERR_DEVICE;
+    }
+    return RB_OK;
+}
+
+int rb_comm_init_rank(rb_engine* e, const uint8_t id[RB_COMM_ID_BYTES], uint32_t rank, uint32_t nranks) {
+    if (!e || !id) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) return fail(e, RB_ERR_INVALID_OPTIONS, "rb_comm_init_rank is for single-device engines");
+    const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
+    if (nranks != sc || rank != (sc > 1 ? e->opt.shard_rank : 0u))
+        return fail(e, RB_ERR_INVALID_OPTIONS, "communicator rank %u of %u does not match shard %u of %u", rank, nranks,
+                    e->opt.shard_rank, sc);
+    set_device(e);
+    std::string why;
+    if (rb::gather_init_rank(e->net, e->device, id, rank, nranks, why)) return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
+    return RB_OK;
+}
+
 void rb_destroy(rb_engine* e) {
     if (!e) return;
+    if (is_group(e)) {
+        for (auto& p : e->parts) {
+            set_device(p.get());
+            if (p->stream) (void)hipStreamSynchronize(p->stream);
+        }
+        rb::gather_destroy(e->net);
+        for (auto& p : e->parts) rb_destroy(p.release());
+        delete e;
+        return;
+    }
     set_device(e);
+    // every launch, copy and event record of this engine was queued on its one stream: when that has
+    // drained nothing on the device refers to the buffers, events or communicator any more
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    rb::gather_destroy(e->net);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    for (FrameSlot& s : e->slot)
+        if (s.done) (void)hipEventDestroy(s.done);
     for (hipEvent_t x : e->ev_pool) (void)hipEventDestroy(x);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
-const char* rb_last_error(const rb_engine* e) { return e ? e->error.c_str() : g_create_error.c_str(); }
+const char* rb_last_error(const rb_engine* e) {
+    if (!e) return g_create_error.c_str();
+    // the text stays valid until the next failing call on this engine (rb_abi.h); the lock only orders
+    // this read against a concurrent writer's assignment
+    std::lock_guard<std::mutex> g(e->err_mu);
+    return e->error.c_str();
+}
 
 int rb_update(rb_engine* e, const rb_config* cfg) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) return group_update(e, cfg);
     set_device(e);
     return update_locked(e, cfg);
 }
@@ -814,6 +1214,7 @@ int rb_update(rb_engine* e, const rb_config* cfg) {
 int rb_render(rb_engine* e, uint8_t* rgba_out) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) return group_render(e, rgba_out);
     set_device(e);
     return render_locked(e, rgba_out);
 }
@@ -821,6 +1222,10 @@ int rb_render(rb_engine* e, uint8_t* rgba_out) {
 int rb_render_config(rb_engine* e, const rb_config* cfg, uint8_t* rgba_out) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        const int rc = group_update(e, cfg);
+        return rc ? rc : group_render(e, rgba_out);
+    }
     set_device(e);
     int rc = update_locked(e, cfg);
     if (rc) return rc;
@@ -830,6 +1235,17 @@ int rb_render_config(rb_engine* e, const rb_config* cfg, uint8_t* rgba_out) {
 int rb_iter_begin(rb_engine* e, const rb_config* cfg) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        int rc = group_update(e, cfg);
+        if (rc) return rc;
+        for (auto& p : e->parts) {
+            PART_TRY(e, p.get(), require_ready(p.get()));
+            p->prh.current_pass = 0;
+            p->iter_initialized = false;
+        }
+        e->prh = e->parts[0]->prh;
+        return RB_OK;
+    }
     set_device(e);
     int rc = update_locked(e, cfg);
     if (rc) return rc;
@@ -837,37 +1253,23 @@ int rb_iter_begin(rb_engine* e, const rb_config* cfg) {
     if (rc) return rc;
     e->prh.current_pass = 0;       // lib.rs:91
     e->iter_initialized = false;   // RaytracerFrameIterator::new (lib.rs:144-150)
+    e->spec_valid = false;
     return RB_OK;
 }
 
 int rb_iter_has_next(rb_engine* e) {
     if (!e) return 0;
     std::lock_guard<std::mutex> lock(e->mu);
-    return e->prh.current_pass < e->prh.total_passes ? 1 : 0;  // lib.rs:153-156
+    const rb_engine* s = is_group(e) ? e->parts[0].get() : e;
+    return s->prh.current_pass < s->prh.total_passes ? 1 : 0;  // lib.rs:153-156
 }
 
 int rb_iter_next(rb_engine* e, uint8_t* rgba_out) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) return group_iter_next(e, rgba_out);
     set_device(e);
-    if (!(e->prh.current_pass < e->prh.total_passes))
-        return fail(e, RB_ERR_NO_MORE_FRAMES, "No more frames available");  // lib.rs:170-177
-    int rc = require_ready(e);
-    if (rc) return rc;
-    if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
-    if (!e->iter_initialized) {  // lib.rs:181-192
-        rc = clear_accum(e);
-        if (rc) return rc;
-        e->iter_initialized = true;
-    }
-    const uint32_t left = e->prh.total_passes - e->prh.current_pass;
-    const uint32_t n = std::min(std::max(e->iter_passes_per_frame, 1u), left);
-    rc = dispatch(e, e->prh.current_pass, n);  // lib.rs:200-203 (n = 1 there)
-    if (rc) return rc;
-    rc = read_rgba(e, rgba_out);  // lib.rs:205
-    if (rc) return rc;
-    e->prh.current_pass += n;  // lib.rs:213
-    return accumulate_timing(e);
+    return iter_next_locked(e, rgba_out);
 }
 
 void rb_iter_destroy(rb_engine* e) { (void)e; }  // lib.rs:231-233: logs only
@@ -881,10 +1283,8 @@ int rb_iter_set_passes_per_frame(rb_engine* e, uint32_t n) {
 
 int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
-    if (!e->have_uniforms) {
-        e->error = "Uniforms must be initialized";  // gpu_wrapper.rs:313,321
-        return RB_ERR_UNIFORMS_NOT_INITIALIZED;
-    }
+    std::lock_guard<std::mutex> lock(const_cast<rb_engine*>(e)->mu);
+    if (!e->have_uniforms) return fail(e, RB_ERR_UNIFORMS_NOT_INITIALIZED, "Uniforms must be initialized");  // gpu_wrapper.rs:313,321
     if (width) *width = e->width;
     if (height) *height = e->height;
     return RB_OK;
@@ -893,6 +1293,13 @@ int rb_get_size(const rb_engine* e, uint32_t* width, uint32_t* height) {
 int rb_clear(rb_engine* e) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        for (auto& p : e->parts) {
+            PART_TRY(e, p.get(), require_ready(p.get()));
+            PART_TRY(e, p.get(), clear_accum(p.get()));
+        }
+        return RB_OK;
+    }
     set_device(e);
     int rc = require_ready(e);
     if (rc) return rc;
@@ -902,15 +1309,31 @@ int rb_clear(rb_engine* e) {
 int rb_dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        for (auto& p : e->parts) {
+            PART_TRY(e, p.get(), require_ready(p.get()));
+            p->spec_valid = false;
+            PART_TRY(e, p.get(), dispatch(p.get(), first_pass, n_passes, p->cur, p->cur));
+        }
+        return RB_OK;
+    }
     set_device(e);
     int rc = require_ready(e);
     if (rc) return rc;
-    return dispatch(e, first_pass, n_passes);
+    e->spec_valid = false;
+    return dispatch(e, first_pass, n_passes, e->cur, e->cur);
 }
 
 int rb_sync(rb_engine* e) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        for (auto& p : e->parts) {
+            set_device(p.get());
+            HIP_TRY(e, hipStreamSynchronize(p->stream));
+        }
+        return RB_OK;
+    }
     set_device(e);
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RB_OK;
@@ -919,6 +1342,10 @@ int rb_sync(rb_engine* e) {
 int rb_read_rgba(rb_engine* e, uint8_t* rgba_out) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+        return group_deliver(e, rgba_out);
+    }
     set_device(e);
     int rc = require_ready(e);
     if (rc) return rc;
@@ -928,26 +1355,54 @@ int rb_read_rgba(rb_engine* e, uint8_t* rgba_out) {
 int rb_read_accumulation(rb_engine* e, float* accum_out) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (!accum_out) return fail(e, RB_ERR_NULL_ARGUMENT, "accum_out is NULL");
+    if (is_group(e)) {
+        // debugging / checkpoint path: every part's rows through the host, in image order
+        rb_engine* p0 = e->parts[0].get();
+        const uint32_t w = p0->width, h = p0->height, sr = p0->opt.stripe_rows ? p0->opt.stripe_rows : rb::kDefaultStripeRows;
+        const uint32_t n = static_cast<uint32_t>(e->parts.size());
+        std::vector<float> tmp(static_cast<size_t>(w) * p0->padded_rows * 4);
+        for (uint32_t r = 0; r < n; ++r) {
+            rb_engine* p = e->parts[r].get();
+            PART_TRY(e, p, require_ready(p));
+            HIP_TRY(e, hipStreamSynchronize(p->stream));
+            HIP_TRY(e, hipMemcpy(tmp.data(), p->slot[p->cur].accum.ptr, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (uint32_t lr = 0; lr < p->padded_rows; ++lr) {
+                const uint32_t y = ((lr / sr) * n + r) * sr + lr % sr;
+                if (y < h) std::memcpy(accum_out + static_cast<size_t>(y) * w * 4, tmp.data() + static_cast<size_t>(lr) * w * 4, static_cast<size_t>(w) * 16);
+            }
+        }
+        return RB_OK;
+    }
     set_device(e);
     int rc = require_ready(e);
     if (rc) return rc;
-    if (!accum_out) return fail(e, RB_ERR_NULL_ARGUMENT, "accum_out is NULL");
     const uint32_t rows = (e->opt.shard_count > 1) ? e->padded_rows : e->height;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(accum_out, e->accum.ptr, static_cast<size_t>(e->width) * rows * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(accum_out, e->slot[e->cur].accum.ptr, static_cast<size_t>(e->width) * rows * 16, hipMemcpyDeviceToHost));
     return RB_OK;
 }
 
 int rb_device_rgba(rb_engine* e, void** d_ptr, size_t* bytes) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
-    if (d_ptr) *d_ptr = e->out_rgba.ptr;
+    if (is_group(e)) {  // the assembled frame on the root device (valid after a render / iterator step)
+        if (d_ptr) *d_ptr = rb::gather_frame_ptr(e->net);
+        if (bytes) *bytes = static_cast<size_t>(e->width) * e->height * 4;
+        return RB_OK;
+    }
+    if (d_ptr) *d_ptr = e->slot[e->cur].rgba.ptr;
     if (bytes) *bytes = static_cast<size_t>(e->width) * e->padded_rows * 4;
     return RB_OK;
 }
 
 int rb_local_rows(const rb_engine* e, uint32_t* rows, uint32_t* padded_rows) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
+    if (is_group(e)) {  // the handle delivers whole frames
+        if (rows) *rows = e->height;
+        if (padded_rows) *padded_rows = e->height;
+        return RB_OK;
+    }
     const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
     const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     uint32_t owned = e->height;
@@ -963,6 +1418,7 @@ int rb_local_rows(const rb_engine* e, uint32_t* rows, uint32_t* padded_rows) {
 
 int rb_global_row(const rb_engine* e, uint32_t local_row, uint32_t* global_row) {
     if (!e || !global_row) return RB_ERR_NULL_ARGUMENT;
+    if (is_group(e)) { *global_row = local_row; return RB_OK; }
     const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
     const uint32_t sr = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     if (sc == 1) { *global_row = local_row; return RB_OK; }
@@ -994,12 +1450,38 @@ uint32_t rb_shard_global_row(uint32_t shard_rank, uint32_t shard_count, uint32_t
     return ((local_row / sr) * sc + shard_rank) * sr + local_row % sr;
 }
 
+static int part_stats(rb_engine* e, rb_stats* out);
+
 int rb_get_stats(rb_engine* e, rb_stats* out) {
     if (!e || !out) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {  // work counters add up; the devices run side by side, so times are the slowest part's
+        rb_stats sum{};
+        for (auto& p : e->parts) {
+            rb_stats s{};
+            PART_TRY(e, p.get(), part_stats(p.get(), &s));
+            sum.segments += s.segments; sum.paths += s.paths; sum.nodes_popped += s.nodes_popped;
+            sum.tris_tested += s.tris_tested; sum.spheres_tested += s.spheres_tested;
+            sum.lights_tested += s.lights_tested; sum.mesh_hits += s.mesh_hits;
+            sum.launches = std::max(sum.launches, s.launches);
+            sum.kernel_ms = std::max(sum.kernel_ms, s.kernel_ms);
+            sum.trace_ms = std::max(sum.trace_ms, s.trace_ms);
+            sum.accumulate_ms = std::max(sum.accumulate_ms, s.accumulate_ms);
+        }
+        *out = sum;
+        return RB_OK;
+    }
     set_device(e);
+    return part_stats(e, out);
+}
+
+static int part_stats(rb_engine* e, rb_stats* out) {
     unsigned long long c[rb::C_COUNT];
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    {
+        const int rc = accumulate_timing(e);
+        if (rc) return rc;
+    }
     HIP_TRY(e, hipMemcpy(c, e->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     e->stats.segments = c[rb::C_SEGMENTS];
     e->stats.paths = c[rb::C_PATHS];
@@ -1012,10 +1494,20 @@ int rb_get_stats(rb_engine* e, rb_stats* out) {
     return RB_OK;
 }
 
+static int part_reset_stats(rb_engine* e);
+
 int rb_reset_stats(rb_engine* e) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        for (auto& p : e->parts) PART_TRY(e, p.get(), part_reset_stats(p.get()));
+        return RB_OK;
+    }
     set_device(e);
+    return part_reset_stats(e);
+}
+
+static int part_reset_stats(rb_engine* e) {
     HIP_TRY(e, hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream));
     e->stats = rb_stats{};
     return RB_OK;
@@ -1024,6 +1516,14 @@ int rb_reset_stats(rb_engine* e) {
 int rb_last_dispatch_ms(rb_engine* e, float* ms) {
     if (!e || !ms) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
+    if (is_group(e)) {
+        *ms = 0.0f;
+        for (auto& p : e->parts) {
+            PART_TRY(e, p.get(), accumulate_timing(p.get()));
+            *ms = std::max(*ms, p->last_dispatch_ms);
+        }
+        return RB_OK;
+    }
     set_device(e);
     int rc = accumulate_timing(e);
     if (rc) return rc;
@@ -1045,11 +1545,15 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris, rb_bvh_node* nodes_
     return RB_OK;
 }
 
-const char* rb_version(void) { return "renderbaby-hip 0.1 (gfx950)"; }
+const char* rb_version(void) { return "renderbaby-hip 0.2 (gfx950)"; }
 
-const char* rb_last_kernel_name(const rb_engine* e) { return e ? e->last_kernel_name : ""; }
+const char* rb_last_kernel_name(const rb_engine* e) {
+    if (!e) return "";
+    return is_group(e) ? e->parts[0]->last_kernel_name : e->last_kernel_name;
+}
 
 const char* rb_fast_bvh_builder(const rb_engine* e, float* build_ms) {
+    if (e && is_group(e)) e = e->parts[0].get();
     if (build_ms) *build_ms = e ? e->fast_build_ms : 0.0f;
     return (e && e->fast_ready) ? e->fast_builder : "";
 }

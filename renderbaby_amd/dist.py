@@ -63,20 +63,31 @@ class ShardedRenderer:
     [H, W, 4] uint8 tensor there, None elsewhere)."""
 
     def __init__(self, scene, rank=0, world=1, device=0, stripe_rows=DEFAULT_STRIPE_ROWS, kernel=0,
-                 passes_per_launch=0, stats=False, host_gather=False, fast_bvh=False, device_bvh=False):
+                 passes_per_launch=0, stats=False, host_gather=False, library_gather=False, **engine_kw):
+        """``library_gather``: the exchange runs inside librenderbaby_hip.so (rb_comm_init_rank: one RCCL
+        gather per frame, de-interleave and read-back on rank 0); torch.distributed only hands the communicator
+        id round.  Otherwise the stripes are gathered with torch.distributed (``host_gather``: as CPU tensors,
+        the gloo rehearsal)."""
         import torch
         from .engine import Engine, RenderConfig
         self.torch = torch
         self.scene, self.rank, self.world, self.device = scene, rank, world, device
         self.stripe_rows = stripe_rows
         self.host_gather = host_gather  # gloo rehearsal: gather CPU copies instead of device memory
+        self.library_gather = library_gather and world > 1
         rc = RenderConfig.from_scene(scene)
         self.engine = Engine.new(rc, device=device, shard_rank=rank, shard_count=world, stripe_rows=stripe_rows,
-                                 kernel=kernel, passes_per_launch=passes_per_launch, stats=stats, fast_bvh=fast_bvh,
-                                 device_bvh=device_bvh)
+                                 kernel=kernel, passes_per_launch=passes_per_launch, stats=stats, **engine_kw)
         self.engine.update(rc)
         self.width, self.height = scene.width, scene.height
         self.owned, self.padded = shard_layout(self.height, rank, world, stripe_rows)
+        if self.library_gather:
+            import torch.distributed as dist
+            box = [Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.engine.comm_init_rank(box[0], rank, world)
+            self.local = self.gather_list = None
+            return
         ptr, nbytes = self.engine.device_rgba()
         rows = self.padded if world > 1 else self.height
         assert nbytes >= rows * self.width * 4
@@ -93,6 +104,9 @@ class ShardedRenderer:
         e.sync()  # the engine has its own stream; the gather below runs on torch's
 
     def step(self):
+        if self.library_gather:   # rb_render: all passes, the RCCL gather, the frame on rank 0 (numpy) / None
+            f = self.engine.render_current()
+            return None if f is None else f.pixels
         self.render_local()
         if self.world == 1:
             return self.local

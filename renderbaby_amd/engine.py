@@ -169,7 +169,12 @@ class Engine:
     """``engine_pathtracer::Engine`` for the HIP backend."""
 
     def __init__(self, rc: RenderConfig, device=-1, shard_rank=0, shard_count=1, stripe_rows=0,
-                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0, no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False, device_lbvh=False):
+                 passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0,
+                 no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False,
+                 device_lbvh=False, reference_walk=False, host_bvh=False, devices=None, gather_peer_copy=False,
+                 no_run_ahead=False, own_tree=False):
+        """``devices`` (list of HIP ordinals): one handle over several devices of this process
+        (rb_create_multi): rows sharded in stripes, one RCCL gather per delivered frame."""
         self._lib = load()
         cfg, keep = rc.to_c()
         opt = abi.Options()
@@ -177,18 +182,30 @@ class Engine:
         opt.shard_rank, opt.shard_count, opt.stripe_rows = shard_rank, shard_count, stripe_rows
         opt.passes_per_launch = passes_per_launch
         opt.kernel = kernel
+        # fast_bvh / host_bvh: the library's own tree, built on the host; device_bvh / device_lbvh: built on the
+        # device; own_tree: the library's tree with the builder left to the library (by triangle count)
+        host_bvh = host_bvh or fast_bvh
+        own_tree = own_tree or host_bvh or device_bvh or device_lbvh
         opt.flags = (abi.FLAG_STATS if stats else 0) | (abi.FLAG_NO_SPHERE_BVH if no_sphere_bvh else 0) \
-            | (abi.FLAG_FAST_BVH if (fast_bvh or device_bvh or device_lbvh) else 0) | (abi.FLAG_DEVICE_BVH if (device_bvh or device_lbvh) else 0) | (abi.FLAG_DEVICE_LBVH if device_lbvh else 0)
+            | (abi.FLAG_FAST_BVH if own_tree else 0) | (abi.FLAG_DEVICE_BVH if (device_bvh or device_lbvh) else 0) \
+            | (abi.FLAG_DEVICE_LBVH if device_lbvh else 0) | (abi.FLAG_REFERENCE_WALK if reference_walk else 0) \
+            | (abi.FLAG_HOST_BVH if host_bvh else 0) | (abi.FLAG_GATHER_PEER_COPY if gather_peer_copy else 0) \
+            | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[3] = 1 if no_leaf_stepping else 0   # ablation: per-segment traversal for multi-node trees
         opt._reserved[4] = int(lds_mode)   # LDS staging of small meshes: 0 = when it fits, 1 = never
-        self._h = self._lib.rb_create_ex(C.byref(cfg), C.byref(opt))
+        if devices is not None:
+            devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            self._h = self._lib.rb_create_multi(C.byref(cfg), C.byref(opt), devs, len(devices))
+        else:
+            self._h = self._lib.rb_create_ex(C.byref(cfg), C.byref(opt))
         del keep
         if not self._h:
             msg = self._lib.rb_last_error(None)
             raise RenderError(abi.ERR and 16, (msg or b"rb_create failed").decode())
         self.shard_count = max(shard_count, 1)
+        self.comm_rank = None   # set by comm_init_rank: rank 0 then receives whole frames
 
     @classmethod
     def new(cls, rc, **kw):
@@ -222,15 +239,42 @@ class Engine:
 
     def _frame_shape(self):
         w, h = self.size()
-        if self.shard_count > 1:
+        if self.shard_count > 1 and self.comm_rank is None:
             h = self.local_rows()[1]
         return w, h
+
+    # ---- one process per device: the stripes are gathered to rank 0 inside rb_render / rb_iter_next
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        rc = load().rb_comm_unique_id(buf)
+        if rc:
+            raise RenderError(rc, (load().rb_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, comm_id: bytes, rank: int, nranks: int):
+        buf = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._check(self._lib.rb_comm_init_rank(self._h, buf, rank, nranks))
+        self.comm_rank = rank
 
     def render(self, rc: RenderConfig) -> Frame:
         cfg, keep = rc.to_c()
         self._check(self._lib.rb_update(self._h, C.byref(cfg)))
         del keep
         w, h = self._frame_shape()
+        if self.comm_rank not in (None, 0):   # a non-root rank of a process group: its stripes go to rank 0
+            self._check(self._lib.rb_render(self._h, None))
+            return None
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self._lib.rb_render(self._h, out.ctypes.data))
+        return Frame(w, h, out)
+
+    def render_current(self) -> Frame:
+        """rb_render without an update: all passes of the scene the engine already holds."""
+        w, h = self._frame_shape()
+        if self.comm_rank not in (None, 0):
+            self._check(self._lib.rb_render(self._h, None))
+            return None
         out = np.empty((h, w, 4), dtype=np.uint8)
         self._check(self._lib.rb_render(self._h, out.ctypes.data))
         return Frame(w, h, out)
@@ -314,6 +358,9 @@ class FrameIterator:
 
     def next(self) -> Frame:
         w, h = self._e._frame_shape()
+        if self._e.comm_rank not in (None, 0):
+            self._e._check(self._e._lib.rb_iter_next(self._e._h, None))
+            return None
         out = np.empty((h, w, 4), dtype=np.uint8)
         self._e._check(self._e._lib.rb_iter_next(self._e._h, out.ctypes.data))
         return Frame(w, h, out)

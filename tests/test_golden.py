@@ -33,7 +33,7 @@ def test_hip_reproduces_golden(path, kernel):
     from renderbaby_amd import Engine, RenderConfig
     scene, accum, rgba, stats = _oracle.load_golden(path)
     rc = RenderConfig.from_scene(scene)
-    eng = Engine.new(rc, kernel=kernel, stats=True)
+    eng = Engine.new(rc, kernel=kernel, stats=True, reference_walk=True)   # the golden counters are the reference walk's
     frame = eng.render(rc)
     acc = eng.read_accumulation()
     st = eng.stats()

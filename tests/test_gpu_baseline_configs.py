@@ -1,0 +1,99 @@
+"""BASELINE.json configurations 2, 4 and 5 in the regimes the bench line is quoted on, compared
+with the oracle ("untested configurations"):
+
+* C2 at its real 1024 spp -- default launch chunking and the single 2.1e9-item launch (1.1 % below
+  the stream kernels' 2^31 item limit, a 34 GB colour buffer): 8 rows of the accumulation against
+  the oracle plus the exact segment count of the frame;
+* C4 with its real 10^6 spheres at 4096 x 4096: a centre window against the oracle's linear scan
+  (shader.wgsl:574-586) -- tree depth, margins and sph_id indexing at scale;
+* C5's 1 048 576-triangle mesh at 3840 x 2160, depth 16: rows against the oracle for the reference
+  walk and for the library's own tree (host- and device-built), and whole-frame equality of the walks.
+
+The oracle legs are sized to finish in seconds on the GPU box's host cores."""
+import numpy as np
+import pytest
+
+from renderbaby_amd import Engine, RenderConfig, abi, scenes
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+
+C2_SEGMENTS = 10_946_472_967   # per frame; the figure every C2 bench line divides by
+
+
+@pytest.fixture(scope="module")
+def c2_oracle_rows():
+    s = scenes.cornell_c2()
+    rows = (536, 544)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows)
+    return s, rows, o_acc, o_rgba, o_st
+
+
+@pytest.mark.parametrize("budget_mib", [0, 40960], ids=["default-budget", "one-launch"])
+def test_c2_at_1024_spp_matches_the_oracle(c2_oracle_rows, budget_mib):
+    s, rows, o_acc, o_rgba, o_st = c2_oracle_rows
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, color_budget_mib=budget_mib)
+    f = e.render(rc)
+    acc = e.read_accumulation()
+    st = e.stats()
+    assert e.last_kernel_name() == "k_trace"
+    e.close()
+    if budget_mib:
+        assert st["launches"] == 1     # the whole frame is one launch of 2 123 366 400 items
+    else:
+        assert st["launches"] > 1      # default budget: the frame is cut into several launches
+    r0, r1 = rows
+    assert np.array_equal(acc[r0:r1].view(np.uint32), o_acc[r0:r1].view(np.uint32))
+    assert np.array_equal(f.pixels[r0:r1], o_rgba[r0:r1])
+    assert st["paths"] == 1920 * 1080 * 1024
+    assert st["segments"] == C2_SEGMENTS
+    assert np.all(acc[..., 3] == 1024.0) and np.all(f.pixels[..., 3] == 255)
+
+
+def test_c4_million_spheres_window_matches_the_linear_scan():
+    s = scenes.spheres_scene(spp=1)   # 10^6 spheres, 4096 x 4096, depth 5
+    assert len(s.spheres) == 1_000_000 and (s.width, s.height) == (4096, 4096)
+    rows, cols = (2040, 2048), (2016, 2080)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows, cols=cols)
+    assert o_st["spheres_tested"] == o_st["segments"] * 1_000_000   # the oracle really scanned them all
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc)
+    f = e.render(rc)
+    acc = e.read_accumulation()
+    st = e.stats()
+    assert e.last_kernel_name() == "k_trace_sph"
+    e.close()
+    win = (slice(*rows), slice(*cols))
+    assert np.array_equal(acc[win].view(np.uint32), o_acc[win].view(np.uint32))
+    mirrored = (slice(*rows), slice(s.width - cols[1], s.width - cols[0]))   # read_pixels mirrors x
+    assert np.array_equal(f.pixels[mirrored], o_rgba[mirrored])
+    assert st["paths"] == 4096 * 4096
+
+
+def test_c5_million_triangle_mesh_matches_the_oracle():
+    s = scenes.mesh_c5().with_params(spp=1)   # 1 048 576 + 2 triangles, 3840 x 2160, depth 16
+    assert len(s.bvh_triangles) == 1_048_578 and (s.width, s.height) == (3840, 2160)
+    assert int(s.uniforms["max_depth"][0]) == 16
+    rows = (1500, 1508)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows)
+    assert o_st["mesh_hits"] > 0
+    rc = RenderConfig.from_scene(s)
+    out = {}
+    for mode, kw in (("reference-walk", dict(reference_walk=True)), ("host-sah", dict(host_bvh=True)),
+                     ("device-ploc", dict(device_bvh=True))):
+        e = Engine.new(rc, **kw)
+        f = e.render(rc)
+        out[mode] = (e.read_accumulation(), f.pixels, e.stats()["segments"], e.last_kernel_name())
+        if mode != "reference-walk":
+            assert e.fast_bvh_builder()[0] == mode
+        e.close()
+    assert out["reference-walk"][3] == "k_trace_bvh" and out["host-sah"][3] == "k_trace_fast"
+    r0, r1 = rows
+    for mode, (acc, px, seg, _) in out.items():
+        assert np.array_equal(acc[r0:r1].view(np.uint32), o_acc[r0:r1].view(np.uint32)), mode
+        assert np.array_equal(px[r0:r1], o_rgba[r0:r1]), mode
+    for mode in ("host-sah", "device-ploc"):
+        diff = (out["reference-walk"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
+        assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ from the reference walk"
+        assert out[mode][2] == out["reference-walk"][2]

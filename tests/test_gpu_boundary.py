@@ -213,7 +213,8 @@ def test_iterator_delivering_every_n_passes():
     eng.close()
 
 
-@pytest.mark.parametrize("kw", [dict(fast_bvh=True), dict(device_bvh=True), dict()], ids=["host-sah", "device-ploc", "exact"])
+@pytest.mark.parametrize("kw", [dict(fast_bvh=True), dict(device_bvh=True), dict(reference_walk=True), dict()],
+                         ids=["host-sah", "device-ploc", "reference-walk", "default"])
 def test_scene_updates_rebuild_the_library_trees(kw):
     # Change::Update of the BVH / triangle / sphere fields must rebuild everything derived from them:
     # prepared triangles, the opt-in walk's tree (host or device built), the sphere tree

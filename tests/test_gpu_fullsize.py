@@ -61,7 +61,7 @@ def test_c2_size_properties():
 def test_c3_mesh_subrectangle_matches_oracle():
     s = scenes.mesh_scene(112, 112, 1920, 1080, 2, 5)  # the 50 176-triangle mesh at full resolution
     rc = RenderConfig.from_scene(s)
-    e = Engine.new(rc, stats=True)
+    e = Engine.new(rc, stats=True, reference_walk=True)
     e.render(rc)
     acc = e.read_accumulation()
     e.close()
@@ -76,7 +76,8 @@ def test_c3_fast_bvh_equals_reference_walk_on_the_full_frame():
     rc = RenderConfig.from_scene(s)
     out = {}
     for mode in ("exact", "host-sah", "device-ploc", "device-lbvh"):
-        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=mode.startswith("device"), device_lbvh=(mode == "device-lbvh"))
+        e = Engine.new(rc, reference_walk=(mode == "exact"), host_bvh=(mode == "host-sah"), device_bvh=mode.startswith("device"),
+                       device_lbvh=(mode == "device-lbvh"))
         e.render(rc)
         out[mode] = (e.read_accumulation(), e.stats()["segments"])
         assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
@@ -96,7 +97,7 @@ def test_reference_lamp_scene_fast_walk_equals_reference_walk_at_full_size():
     rc = RenderConfig.from_scene(s)
     out = {}
     for mode in ("exact", "host-sah", "device-ploc"):
-        e = Engine.new(rc, fast_bvh=(mode != "exact"), device_bvh=(mode == "device-ploc"))
+        e = Engine.new(rc, reference_walk=(mode == "exact"), host_bvh=(mode == "host-sah"), device_bvh=(mode == "device-ploc"))
         e.render(rc)
         out[mode] = (e.read_accumulation(), e.stats()["segments"])
         e.close()

@@ -15,7 +15,17 @@ pytestmark = pytest.mark.gpu
 KERNELS = [abi.KERNEL_PIXEL, abi.KERNEL_QUEUE, abi.KERNEL_STREAM]
 
 
+_WALK_KW = ("reference_walk", "fast_bvh", "host_bvh", "device_bvh", "device_lbvh", "own_tree")
+
+
+def _ref(kw):
+    """The tests that compare work counters with the oracle's (or name the reference-walk kernels) pin the
+    reference walk; the library's own tree -- the default for multi-node meshes -- has its own tests."""
+    return kw if any(k in kw for k in _WALK_KW) else dict(kw, reference_walk=True)
+
+
 def _hip(scene, kernel, stats=True, **kw):
+    kw = _ref(kw)
     rc = RenderConfig.from_scene(scene)
     eng = Engine.new(rc, kernel=kernel, stats=stats, **kw)
     frame = eng.render(rc)
@@ -68,7 +78,7 @@ def test_leaf_stepped_walk_from_lds_and_from_l2(grid, lds_mode, name):
     # lds_mode = 1, walk the same tree through L1/L2.  Same bits either way.
     s = scenes.mesh_scene(grid, grid, 64, 40, 3, 5, seed=grid)
     rc = RenderConfig.from_scene(s)
-    eng = Engine.new(rc, stats=True, lds_mode=lds_mode)
+    eng = Engine.new(rc, stats=True, lds_mode=lds_mode, reference_walk=True)
     frame = eng.render(rc)
     acc, st = eng.read_accumulation(), eng.stats()
     assert eng.last_kernel_name() == name
@@ -173,8 +183,8 @@ def _scene_for(which):
 
 
 @pytest.mark.parametrize("which,kw,kernel_name", [
-    ("mesh", dict(), "k_trace_bvh_lds"), ("mesh", dict(lds_mode=1), "k_trace_bvh"),
-    ("mesh", dict(fast_bvh=True), "k_trace_fast"), ("mesh", dict(device_bvh=True), "k_trace_fast"),
+    ("mesh", dict(reference_walk=True), "k_trace_bvh_lds"), ("mesh", dict(lds_mode=1, reference_walk=True), "k_trace_bvh"),
+    ("mesh", dict(fast_bvh=True), "k_trace_fast"), ("mesh", dict(own_tree=True), "k_trace_fast"), ("mesh", dict(device_bvh=True), "k_trace_fast"),
     ("mesh", dict(device_lbvh=True), "k_trace_fast"),
     ("spheres", dict(), "k_trace_sph"), ("spheres", dict(no_leaf_stepping=True), "k_trace")])
 def test_stepped_kernels_under_chunking_sharding_and_the_iterator(which, kw, kernel_name):
@@ -324,8 +334,9 @@ def test_degenerate_frame_sizes(w, h):
         assert st["segments"] == o_st["segments"]
 
 
-@pytest.mark.parametrize("which,kw", [("mesh", dict()), ("mesh", dict(lds_mode=1)), ("mesh", dict(fast_bvh=True)),
-                                      ("mesh", dict(device_bvh=True)), ("spheres", dict())])
+@pytest.mark.parametrize("which,kw", [("mesh", dict(reference_walk=True)), ("mesh", dict(lds_mode=1, reference_walk=True)),
+                                      ("mesh", dict(fast_bvh=True)), ("mesh", dict(device_bvh=True)), ("mesh", dict(own_tree=True)),
+                                      ("spheres", dict())])
 @pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 2, 3), (3, 1, 1, 1), (2, 7, 2, 0), (9, 5, 1, 16)])
 def test_stepped_kernels_on_degenerate_frames(which, kw, w, h, spp, depth):
     # one-pixel axes (inf / NaN primary directions), a single sample, depth 0 and a depth beyond any

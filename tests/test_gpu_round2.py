@@ -1,0 +1,183 @@
+"""Round-2 behaviour of the boundary: refused updates leave the previous scene live, the caller's triangle
+count under Keep (shader.wgsl:336), the progressive iterator running one pass ahead of the read-back, and
+several devices behind one handle (rb_create_multi) -- all through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from renderbaby_amd import Change, Engine, RenderConfig, RenderError, abi, scenes
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_again(e):
+    """rb_render without an update: what a host does that keeps rendering after a failed update."""
+    return e.render_current().pixels
+
+
+def test_refused_update_leaves_the_previous_scene_renderable():
+    # validate_scene used to run after the buffers had been overwritten, so a refused tree stayed
+    # live on an engine that still accepted rb_render / rb_iter_next (a GPU hang for a cyclic tree).
+    s = scenes.mesh_scene(12, 12, 24, 16, 2, 3)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, reference_walk=True)
+    good = e.render(rc).pixels.copy()
+    nodes = s.bvh_nodes.copy()
+    nodes[1]["primitive_count"] = 0
+    nodes[1]["left"] = 0   # cycle back to the root
+    nodes[1]["right"] = 0
+    for bad_field, value, code in (("bvh_nodes", nodes, 13), ("bvh_indices", s.bvh_indices[:5].copy(), 13)):
+        bad = RenderConfig(uniforms=Change.update(s.uniforms))
+        setattr(bad, bad_field, Change.create(value))
+        with pytest.raises(RenderError) as ei:
+            e.update(bad)
+        assert ei.value.code == code
+        assert np.array_equal(_render_again(e), good)       # the refused update touched nothing
+    tris = s.bvh_triangles.copy()
+    tris[3]["mesh_index"] = 99
+    with pytest.raises(RenderError) as ei:
+        e.update(RenderConfig(uniforms=Change.update(s.uniforms), bvh_triangles=Change.create(tris)))
+    assert ei.value.code == 7
+    assert np.array_equal(_render_again(e), good)
+    # the iterator of the still-live scene works as well
+    w, h = e.size()
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    cfg, keep = RenderConfig.from_scene(s, create=False).to_c()
+    e._check(e._lib.rb_iter_begin(e._h, C.byref(cfg)))
+    del keep
+    last = None
+    while e._lib.rb_iter_has_next(e._h):
+        e._check(e._lib.rb_iter_next(e._h, out.ctypes.data))
+        last = out.copy()
+    assert np.array_equal(last, good)
+    e.close()
+
+
+@pytest.mark.parametrize("kw", [dict(reference_walk=True), dict(host_bvh=True)], ids=["reference-walk", "own-tree"])
+def test_keep_honours_the_callers_triangle_count(kw):
+    # shader.wgsl:336 skips triangle ids >= uniforms.bvh_triangle_count, and gpu_wrapper.rs:489-495 leaves the
+    # caller's count in force when the triangles are Keep: a uniforms-only update with a smaller count renders
+    # fewer triangles.  The oracle takes its count from the array length: the same scene with the array cut.
+    s = scenes.mesh_scene(10, 10, 32, 20, 2, 3)
+    n = len(s.bvh_triangles)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, **kw)
+    full = e.render(rc).pixels.copy()
+    assert np.array_equal(full, _oracle.render(s)[2])
+    for count in (n // 2, 0, n + 1000):
+        u = s.uniforms.copy()
+        u["bvh_triangle_count"] = count
+        got = e.render(RenderConfig(uniforms=Change.update(u))).pixels.copy()
+        k = min(count, n)
+        cut = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices,
+                           s.bvh_triangles[:k].copy(), s.uvs, s.textures)
+        assert np.array_equal(got, _oracle.render(cut)[2]), count
+    e.close()
+
+
+@pytest.mark.parametrize("per_frame", [1, 3])
+def test_iterator_running_ahead_delivers_the_same_frames(per_frame):
+    # rb_iter_next starts the next pass group on the second frame slot before it copies the current frame out
+    s = scenes.feature_scene(40, 24, 7, 4)
+    rc = RenderConfig.from_scene(s)
+    frames = {}
+    for mode, kw in (("ahead", dict()), ("plain", dict(no_run_ahead=True))):
+        e = Engine.new(rc, **kw)
+        it = e.frame_iterator(rc, passes_per_frame=per_frame)
+        frames[mode] = [f.pixels.copy() for f in it]
+        acc = e.read_accumulation()
+        st = e.stats()
+        assert st["paths"] == 40 * 24 * 7
+        e.close()
+        o_acc, _, o_rgba, _ = _oracle.render(s)
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), mode
+        assert np.array_equal(frames[mode][-1], o_rgba), mode
+    assert len(frames["ahead"]) == len(frames["plain"]) == -(-7 // per_frame)
+    for a, b in zip(frames["ahead"], frames["plain"]):
+        assert np.array_equal(a, b)
+    # frame k is the running average of the first (k + 1) * per_frame samples
+    k = 1
+    o = _oracle.render(s, 0, min((k + 1) * per_frame, 7))[2]
+    assert np.array_equal(frames["ahead"][k], o)
+
+
+def test_a_pass_started_ahead_is_dropped_when_the_scene_changes():
+    # an update between two rb_iter_next calls: the reference would render the next pass with the NEW scene on
+    # top of the accumulation so far (lib.rs:200-203 after gpu_wrapper.rs:116-300); the pass already running
+    # with the old scene on the other slot must not be delivered
+    a = scenes.cornell(32, 20, 4, 3)
+    b = scenes.cornell(32, 20, 4, 3, seed=5)
+    out = {}
+    for mode, kw in (("ahead", dict()), ("plain", dict(no_run_ahead=True))):
+        e = Engine.new(RenderConfig.from_scene(a), **kw)
+        it = e.frame_iterator(RenderConfig.from_scene(a))
+        f0 = it.next().pixels.copy()
+        e.update(RenderConfig(uniforms=Change.update(b.uniforms), spheres=Change.update(b.spheres)))
+        rest = [f.pixels.copy() for f in it]
+        out[mode] = [f0] + rest
+        e.close()
+    assert len(out["ahead"]) == 4
+    for x, y in zip(out["ahead"], out["plain"]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n,stripe_rows", [(2, 16), (3, 1), (8, 4)])
+def test_multi_device_handle_assembles_the_single_device_frame(n, stripe_rows):
+    # rb_create_multi with n shards.  One GPU is all a test box has: the shards run on device 0 and the stripes
+    # move with the peer-copy transport (RCCL refuses one device twice); the sharding, the gather buffer layout,
+    # the de-interleave kernel and the read-back are the code the RCCL transport uses too.
+    s = scenes.feature_scene(50, 37, 3, 4)
+    rc = RenderConfig.from_scene(s)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    e = Engine.new(rc, devices=[0] * n, stripe_rows=stripe_rows, gather_peer_copy=True, stats=True)
+    f = e.render(rc)
+    assert f.pixels.shape == (37, 50, 4)
+    assert np.array_equal(f.pixels, o_rgba)
+    assert np.array_equal(e.read_accumulation().view(np.uint32), o_acc.view(np.uint32))
+    st = e.stats()
+    assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"]
+    # the progressive iterator through the same handle
+    frames = [fr.pixels.copy() for fr in e.frame_iterator(RenderConfig.from_scene(s, create=False))]
+    assert len(frames) == 3 and np.array_equal(frames[-1], o_rgba)
+    assert np.array_equal(frames[0], _oracle.render(s, 0, 1)[2])
+    # a new resolution through the same handle
+    t = s.with_params(width=33, height=50, spp=2)
+    assert np.array_equal(e.render(RenderConfig(uniforms=Change.update(t.uniforms))).pixels, _oracle.render(t)[2])
+    e.close()
+
+
+def test_multi_device_handle_with_a_mesh_and_the_stream_kernels():
+    s = scenes.mesh_scene(24, 24, 96, 64, 2, 4)
+    rc = RenderConfig.from_scene(s)
+    single = Engine.new(rc)
+    want = single.render(rc).pixels.copy()
+    single.close()
+    e = Engine.new(rc, devices=[0, 0, 0, 0], gather_peer_copy=True)
+    assert np.array_equal(e.render(rc).pixels, want)
+    e.close()
+
+
+def test_rccl_communicator_of_one_rank():
+    # one process per device (rb_comm_unique_id / rb_comm_init_rank): with the one GPU a test box has this is a
+    # communicator of a single rank -- librccl is found and loaded, the id made, the communicator created, the
+    # render goes through the gather path's root side and the communicator is destroyed with the engine
+    s = scenes.cornell(24, 16, 2, 3)
+    rc = RenderConfig.from_scene(s)
+    cid = Engine.comm_unique_id()
+    assert len(cid) == abi.COMM_ID_BYTES and any(cid)
+    e = Engine.new(rc)
+    e.comm_init_rank(cid, 0, 1)
+    assert np.array_equal(e.render(rc).pixels, _oracle.render(s)[2])
+    with pytest.raises(RenderError):
+        e.comm_init_rank(cid, 1, 2)   # does not match the engine's shard geometry
+    e.close()
+
+
+def test_single_device_group_needs_no_communicator():
+    s = scenes.cornell(24, 16, 2, 3)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, devices=[0])
+    assert np.array_equal(e.render(rc).pixels, _oracle.render(s)[2])
+    e.close()

@@ -97,7 +97,7 @@ def test_reference_cornell_fixture_bit_exact_on_gpu(kernel):
     s = _refscenes.ref_cornell(96, 72, 6, 6)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
     rc = RenderConfig.from_scene(s)
-    e = Engine.new(rc, kernel=kernel, stats=True)
+    e = Engine.new(rc, kernel=kernel, stats=True, reference_walk=True)   # the counters below are the reference walk's
     f = e.render(rc)
     acc = e.read_accumulation()
     st = e.stats()
@@ -306,7 +306,7 @@ def test_loaded_scene_file_renders_bit_exact_on_gpu(tmp_path):
     s = scene_io.load_scene(_write_scene_dir(str(tmp_path)), total_samples=6)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
     rc = RenderConfig.from_scene(s)
-    e = Engine.new(rc, stats=True)
+    e = Engine.new(rc, stats=True, reference_walk=True)
     f = e.render(rc)
     acc, st = e.read_accumulation(), e.stats()
     e.close()
@@ -339,8 +339,8 @@ def test_reference_lamp_scene_bit_exact_on_gpu(mode):
     s = _refscenes.ref_lamp(width=96, height=96, spp=2)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
     rc = RenderConfig.from_scene(s)
-    e = Engine.new(rc, stats=True, fast_bvh=(mode != "exact"), device_bvh=mode.startswith("device"),
-                   device_lbvh=(mode == "device-lbvh"))
+    e = Engine.new(rc, stats=True, reference_walk=(mode == "exact"), host_bvh=(mode == "host-sah"),
+                   device_bvh=mode.startswith("device"), device_lbvh=(mode == "device-lbvh"))
     f = e.render(rc)
     acc, st = e.read_accumulation(), e.stats()
     assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)

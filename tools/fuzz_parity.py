@@ -3,7 +3,14 @@ sphere / triangle soups with nasty cases -- tiny, huge, degenerate, coincident, 
 materials, lights, ground, textures, colour hash), every kernel variant, bit for bit.
 
     python tools/fuzz_parity.py [first_seed] [count]
+
+Evidence instead of repetition: a crash leaves every thread's Python stack in
+gpurun_out/fuzz_fault.txt (faulthandler), a scene that takes longer than FUZZ_SCENE_TIMEOUT seconds (default 120)
+dumps every thread's stack to the same file together with the (seed, variant, kernel) it was on, and a mismatch
+writes seed, variant, the differing pixel coordinates and the raw frame / accumulation / oracle arrays to
+gpurun_out/fuzz_mismatch_<seed>_<variant>.npz.
 """
+import faulthandler
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -79,9 +86,11 @@ def random_scene(seed):
 
 
 def variants(scene):
-    v = [("pixel", dict(kernel=abi.KERNEL_PIXEL)), ("queue", dict(kernel=abi.KERNEL_QUEUE)), ("stream", dict())]
+    v = [("pixel", dict(kernel=abi.KERNEL_PIXEL, reference_walk=True)), ("queue", dict(kernel=abi.KERNEL_QUEUE, reference_walk=True)),
+         ("stream", dict(reference_walk=True))]
     if len(scene.bvh_nodes) > 1:
-        v += [("stream-noLDS", dict(lds_mode=1)), ("stream-perseg", dict(no_leaf_stepping=True)), ("fast", dict(fast_bvh=True)),
+        v += [("stream-noLDS", dict(lds_mode=1, reference_walk=True)), ("stream-perseg", dict(no_leaf_stepping=True, reference_walk=True)),
+              ("default", dict()), ("fast", dict(fast_bvh=True)),
               ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
     if len(scene.spheres) > 64:
         v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True))]
@@ -92,17 +101,25 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     bad = 0
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
+    fault = open(os.path.join(outdir, "fuzz_fault.txt"), "a")
+    faulthandler.enable(file=fault, all_threads=True)
+    scene_timeout = float(os.environ.get("FUZZ_SCENE_TIMEOUT", "120"))
     trace = open(os.environ["FUZZ_TRACE"], "w") if os.environ.get("FUZZ_TRACE") else None   # last (seed, variant) started
     for seed in range(first, first + count):
         s = random_scene(seed)
+        fault.write(f"# seed {seed}\n"); fault.flush()
+        faulthandler.dump_traceback_later(scene_timeout, repeat=False, file=fault, exit=False)
         o_acc, _, o_rgba, o_st = _oracle.render(s)
         rc = RenderConfig.from_scene(s)
         for name, kw in variants(s):
             if trace is not None:
                 trace.seek(0); trace.truncate(); trace.write(f"{seed} {name}\n"); trace.flush()
             try:
+                fault.write(f"#   variant {name}\n"); fault.flush()
                 e = Engine.new(rc, stats=True, **kw)
-                frame = e.render(rc); acc = e.read_accumulation(); st = e.stats(); e.close()
+                frame = e.render(rc); acc = e.read_accumulation(); st = e.stats(); kname = e.last_kernel_name(); e.close()
             except Exception as ex:   # a scene the library refuses must be refused by every variant alike
                 print(f"seed {seed} {name}: {type(ex).__name__}: {ex}"); bad += 1; continue
             ok = np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(frame.pixels, o_rgba) \
@@ -110,9 +127,15 @@ def main():
             if not ok:
                 bad += 1
                 nd = int((acc.view(np.uint32) != o_acc.view(np.uint32)).any(axis=-1).sum())
+                np.savez(os.path.join(outdir, f"fuzz_mismatch_{seed}_{name}.npz"), seed=seed, variant=name, kernel=kname,
+                         acc=acc, o_acc=o_acc, rgba=frame.pixels, o_rgba=o_rgba,
+                         acc_diff=np.argwhere((acc.view(np.uint32) != o_acc.view(np.uint32)).any(axis=-1)),
+                         rgba_diff=np.argwhere((frame.pixels != o_rgba).any(axis=-1)),
+                         stats=np.array([st[k] for k in _oracle.STAT_KEYS]), o_stats=np.array([o_st[k] for k in _oracle.STAT_KEYS]))
                 print(f"seed {seed} {name}: MISMATCH ({nd} pixels; segments {st['segments']} vs {o_st['segments']}) "
                       f"[{s.width}x{s.height} spp {s.total_samples} depth {int(s.uniforms[0]['max_depth'])} tris {len(s.bvh_triangles)} "
                       f"nodes {len(s.bvh_nodes)} spheres {len(s.spheres)} lights {len(s.lights)}]")
+        faulthandler.cancel_dump_traceback_later()
         if (seed - first) % 20 == 19:
             print(f"... {seed - first + 1} scenes, {bad} failures so far", flush=True)
     print(f"fuzz: {count} scenes from seed {first}: {bad} failures")

@@ -36,6 +36,10 @@ def test_two_ranks_reproduce_the_single_rank_frame(tmp_path):
     assert one["config"]["segments_per_step"] == two["config"]["segments_per_step"]
     assert two["config"]["paths_per_step"] == 512 * 512 * 64
     for j in (one, two):
-        assert j["unit"] == "Msamples/s" and j["value"] > 0 and j["roofline"]["achieved"] > 0
+        assert j["unit"] == "Msamples/s" and j["value"] > 0
+        roof = j["roofline"]
+        assert roof["kernel_ms"] > 0 and roof["algorithmic"]["GBps"] > 0
+        # the binding ceiling comes from a PMC profile of THIS build or not at all: never above 1
+        assert roof["frac"] is None or 0.0 < roof["frac"] <= 1.0
         assert j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "strong"
     assert np.array_equal(np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy"))

@@ -352,8 +352,16 @@ int rb_read_rgba(rb_engine* e, uint8_t* rgba_out);
 /* Copy the f32 accumulation (vec4 per pixel, shader x order, local stripe
  * order) to the host: local_rows*width*4 floats. */
 int rb_read_accumulation(rb_engine* e, float* accum_out);
-/* Device pointer + byte size of the local RGBA8 stripe buffer, for an RCCL
- * gather issued by the caller. */
+/* Page-locked host memory for frames (extension): rb_render / rb_iter_next / rb_read_rgba recognise a
+ * page-locked rgba_out (from here, or registered by the caller with hipHostRegister) and copy into it by DMA on
+ * a second stream, without the staging and host-side copy a pageable destination costs -- with the iterator's
+ * run-ahead pass this is what lets frame delivery run at the compute rate.  Plain malloc'ed buffers keep
+ * working (blocking copy).  Free with rb_host_free. */
+void* rb_host_alloc(size_t bytes);
+void rb_host_free(void* p);
+
+/* Device pointer + byte size of the RGBA8 buffer of the committed frame (a single engine: its local stripe
+ * buffer, valid until the next iterator step; a multi-device handle: the assembled frame on devices[0]). */
 int rb_device_rgba(rb_engine* e, void** d_ptr, size_t* bytes);
 /* Number of image rows this engine owns (== height when not sharded) and
  * the padded row count of the local buffer (equal on every rank). */

@@ -242,34 +242,40 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 }
 
 
-// ------------------------------------------------------------ fast triangle tree --
-// Opt-in (RB_FLAG_FAST_BVH).  The reference walks its 128-triangle-leaf tree without
-// t-culling or ordering (shader.wgsl:282-392); on a 50k-triangle mesh that is ~430 triangle
-// tests per segment.  This builds a second tree over the SAME triangles (binned SAH, <= 4 per
-// leaf, both children's boxes in the parent) that the kernels walk near-child-first with
-// culling.  To keep the reference's winner it also emits, per triangle slot, the reference
-// leaf that holds it and its rank in the reference's visit order, plus a parent array of the
-// reference tree: an improving candidate is accepted only if every reference node from its
-// leaf up to the root passes the reference's own slab test, and equal t resolves by rank.
+// ------------------------------------------------------------ the library's own triangle tree --
+// The reference walks its 128-triangle-leaf tree without t-culling or ordering (shader.wgsl:282-392); on a
+// 50k-triangle mesh that is ~430 triangle tests per segment.  This builds a second tree over the SAME triangles
+// (binned SAH, <= 2 per leaf, both children's boxes in the parent) that the kernels walk near-child-first with
+// culling.  To keep the reference's winner it also emits, per triangle slot, the reference leaf that holds it
+// and its rank in the reference's visit order, plus a parent array of the reference tree: an improving
+// candidate is accepted only if every reference node from its leaf up to the root passes the reference's own
+// slab test, and equal t resolves by rank.
 //
-// How far from its triangle can a hit be reported?  The computed Moller-Trumbore outputs carry
-// absolute errors  du, dv <= e |s| |e2| / |a| ,  dt <= e |s| |e1| |e2| / |a|  with e ~ 7 * 2^-24 and
-// s = origin - v0, so a reported hit lies within  r = e |s| |e1| |e2| / |a|  of the triangle, in
-// space and along the ray.  Each child stores the largest |e1|*|e2| below it and the traversal
-// inflates the child's box by  0.01 * S * that  (S >= |s|: farthest the origin can be from the mesh)
-// plus a slab-rounding margin: every hit with |a| >= 4.2e-5 is then inside every box above its
-// triangle no later than its reported t, and cannot be culled.  Hits with 1e-6 <= |a| < 4.2e-5 (a ray
-// within a fraction of a degree of the triangle's plane, the regime where the reference's own u, v
-// are mostly rounding noise) are not covered by this argument; covering them with the worst-case
-// bound (factor 0.42 instead of 0.01) was tried and makes coarse meshes slower than the reference
-// walk.  Hence "opt-in", and hence the bit-for-bit tests against the reference walk.
+// Culling must never lose a triangle the reference would report as hit, and the reference's f32
+// Moller-Trumbore can report a hit some distance away from the triangle: at most
+// 26 u (|s| + L) L^2 / |a| + ... (rb_device_intersect.hpp, FastWalk::entry).  The traversal
+// turns that into a per-ray margin for each child box from three per-child numbers made here, all rounded
+// outwards: the axis c and half-angle alpha of a cone that contains every triangle normal below the child
+// (either orientation), stored as c and tan(alpha), and invk = max_k (L_k^2 / N_k) / cos(alpha)
+// (L = longer of the two edges at v0, N = |e1 x e2|).  A child whose normals do not fit a cone of less than
+// ~89 degrees, or that holds a triangle with N = 0, gets invk = +inf: it is always entered.
 namespace {
+struct ItemGeom {       // per triangle, in double from the f32 edges the kernels use (e1 = fl(v1 - v0), ...)
+    double n[3];        // unit normal (zero vector if N == 0)
+    double q;           // L^2 / N  (+inf if N == 0)
+};
+struct ChildCone {
+    float c[3], tan_a, invk;
+};
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
 struct FBuilder {
     const std::vector<float>& bmn;   // per item: tight box min (3 floats)
     const std::vector<float>& bmx;
-    const std::vector<float>& e1e2;  // per item |e1| * |e2|
+    const std::vector<ItemGeom>& geo;
     std::vector<uint32_t>& items;    // permuted in place
     std::vector<SphereNode>& nodes;
+    std::vector<FastCone>& cones;    // parallel to nodes
     uint32_t limit;
     uint32_t max_depth = 0;
     uint32_t par_levels = 0;   // levels below this call that may still fork a thread
@@ -288,14 +294,45 @@ struct FBuilder {
         }
     }
     float centroid(uint32_t it, int a) const { return 0.5f * (bmn[it * 3 + a] + bmx[it * 3 + a]); }
-    float amax(size_t first, size_t count) const {
-        float m = 0.0f;
-        for (size_t i = first; i < first + count; ++i) m = std::max(m, e1e2[items[i]]);
-        return m;
-    }
     static float area(const float mn[3], const float mx[3]) {
         const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
         return (x < 0 || y < 0 || z < 0) ? 0.0f : 2.0f * (x * y + y * z + z * x);
+    }
+    // cone of the (unoriented) normals of items [first, first + count), and their largest L^2 / N
+    ChildCone cone(size_t first, size_t count) const {
+        ChildCone out{{0.0f, 0.0f, 0.0f}, 0.0f, kInf};
+        double sum[3] = {0, 0, 0}, ref[3] = {0, 0, 0}, qmax = 0.0;
+        bool have_ref = false;
+        for (size_t i = first; i < first + count; ++i) {
+            const ItemGeom& g = geo[items[i]];
+            if (!(g.q < std::numeric_limits<double>::infinity())) return out;   // a triangle without a normal
+            qmax = std::max(qmax, g.q);
+            if (!have_ref) {
+                for (int a = 0; a < 3; ++a) ref[a] = g.n[a];
+                have_ref = true;
+            }
+            const double sgn = (g.n[0] * ref[0] + g.n[1] * ref[1] + g.n[2] * ref[2]) < 0.0 ? -1.0 : 1.0;
+            for (int a = 0; a < 3; ++a) sum[a] += sgn * g.n[a];
+        }
+        const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+        if (!have_ref || !(len > 1e-9)) return out;
+        double c[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
+        // the stored axis is the f32 rounding of c: measure the cone around THAT vector
+        float cf[3] = {static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2])};
+        const double cl = std::sqrt(double(cf[0]) * cf[0] + double(cf[1]) * cf[1] + double(cf[2]) * cf[2]);
+        double cos_a = 1.0;
+        for (size_t i = first; i < first + count; ++i) {
+            const ItemGeom& g = geo[items[i]];
+            cos_a = std::min(cos_a, std::fabs(g.n[0] * cf[0] + g.n[1] * cf[1] + g.n[2] * cf[2]) / cl);
+        }
+        cos_a = cos_a * (1.0 - 1e-6) - 1e-7;     // the kernels take |d . cf| for |d^ . c|: |cf| is within 1e-7 of 1
+        if (!(cos_a > 0.0175)) return out;       // wider than ~89 degrees: no useful bound
+        const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
+        out.c[0] = cf[0]; out.c[1] = cf[1]; out.c[2] = cf[2];
+        out.tan_a = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
+        out.invk = static_cast<float>(qmax / (0.95 * cos_a) * (1.0 + 1e-5));   // 0.95: |a^| >= 0.95 |a| in the bound's range
+        if (!(out.invk < kInf)) out = ChildCone{{0.0f, 0.0f, 0.0f}, 0.0f, kInf};
+        return out;
     }
 
     uint32_t build(size_t first, size_t count, uint32_t depth) {
@@ -385,18 +422,23 @@ struct FBuilder {
         }
         const uint32_t me = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
+        cones.emplace_back();
         SphereNode n;
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
+        const ChildCone cl = cone(first, mid - first), cr = cone(mid, first + count - mid);
         if (count >= kParallelCount && par_levels > 0u) {
             std::vector<SphereNode> lv, rv;
-            FBuilder lb{bmn, bmx, e1e2, items, lv, limit, 0, par_levels - 1u};
-            FBuilder rb{bmn, bmx, e1e2, items, rv, limit, 0, par_levels - 1u};
+            std::vector<FastCone> lc, rc;
+            FBuilder lb{bmn, bmx, geo, items, lv, lc, limit, 0, par_levels - 1u};
+            FBuilder rb{bmn, bmx, geo, items, rv, rc, limit, 0, par_levels - 1u};
             auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
             uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
             uint32_t lref = fut.get();
             append_subtree(nodes, lv, lref);
+            cones.insert(cones.end(), lc.begin(), lc.end());
             append_subtree(nodes, rv, rref);
+            cones.insert(cones.end(), rc.begin(), rc.end());
             n.left = lref;
             n.right = rref;
             max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
@@ -404,11 +446,14 @@ struct FBuilder {
             n.left = build(first, mid - first, depth + 1);
             n.right = build(mid, first + count - mid, depth + 1);
         }
-        // largest |e1|*|e2| below each child: scales the per-ray inflation of that child's box
-        const float al = amax(first, mid - first), ar = amax(mid, first + count - mid);
-        std::memcpy(&n._pad0, &al, 4);
-        std::memcpy(&n._pad1, &ar, 4);
+        // the two pad words: invk of each child (scales the per-ray inflation of that child's box)
+        std::memcpy(&n._pad0, &cl.invk, 4);
+        std::memcpy(&n._pad1, &cr.invk, 4);
         nodes[me] = n;
+        FastCone fc;
+        fc.l[0] = cl.c[0]; fc.l[1] = cl.c[1]; fc.l[2] = cl.c[2]; fc.l[3] = cl.tan_a;
+        fc.r[0] = cr.c[0]; fc.r[1] = cr.c[1]; fc.r[2] = cr.c[2]; fc.r[3] = cr.tan_a;
+        cones[me] = fc;
         return me;
     }
 };
@@ -452,18 +497,28 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
                     const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
     if (!fast_bvh_prepare(tri_count, indices, index_len, ref_nodes, node_count, out)) return false;
     const std::vector<uint32_t> slots = std::move(out.slots);
-    // ---- tight boxes per item; items are indices into `slots`
+    // ---- tight boxes, normals and L^2 / N per item; items are indices into `slots`
     const size_t n = slots.size();
-    std::vector<float> bmn(n * 3), bmx(n * 3), e1e2(n);
+    std::vector<float> bmn(n * 3), bmx(n * 3);
+    std::vector<ItemGeom> geo(n);
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
         const rb_gpu_triangle& t = tris[indices[slots[i]]];
-        double l1 = 0, l2 = 0;
+        double e1[3], e2[3], l1 = 0, l2 = 0;
         for (int a = 0; a < 3; ++a) {
-            l1 += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);
-            l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
+            e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
+            e2[a] = double(t.v2[a] - t.v0[a]);
+            l1 += e1[a] * e1[a];
+            l2 += e2[a] * e2[a];
         }
-        e1e2[i] = static_cast<float>(std::sqrt(l1) * std::sqrt(l2) * 1.0001);
+        const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+        const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+        ItemGeom g{{0, 0, 0}, std::numeric_limits<double>::infinity()};
+        if (nn > 0.0 && std::isfinite(nn)) {
+            g.n[0] = nx / nn; g.n[1] = ny / nn; g.n[2] = nz / nn;
+            g.q = std::max(l1, l2) / nn * (1.0 + 1e-9);
+        }
+        geo[i] = g;
         for (int a = 0; a < 3; ++a) {
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
@@ -476,19 +531,17 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     // up to 64 threads at the sixth level; RB_HOST_BUILD_SEQUENTIAL=1 (debug) builds on one thread -- the
     // tree is the same either way (tests/test_gpu_parity.py compares the walk's counters)
     const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
-    FBuilder fb{bmn, bmx, e1e2, items, out.nodes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
+    FBuilder fb{bmn, bmx, geo, items, out.nodes, out.cones, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
-    out.cones.assign(out.nodes.size(), FastCone{});
     out.slots.resize(n);
     for (size_t i = 0; i < n; ++i) out.slots[i] = slots[items[i]];
-    const float dx = smx[0] - smn[0], dy = smx[1] - smn[1], dz = smx[2] - smn[2];
-    out.margin = kFastSlabMargin * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-6f;
+    out.margin = 0.0f;
     for (int a = 0; a < 3; ++a) {
         out.bmin[a] = smn[a];
         out.bmax[a] = smx[a];
     }
-    out.root_amax = fb.amax(0, n);
+    out.root_amax = 0.0f;
     return out.depth <= stack_limit;
 }
 

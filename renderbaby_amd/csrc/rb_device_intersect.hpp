@@ -225,27 +225,42 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
     }
 }
 
-// Opt-in fast walk (RB_FLAG_FAST_BVH) of the library's own SAH tree over the same triangles
-// (rb_bvh.cpp, fast_bvh_build): nearer child first, subtrees skipped when missed or entered
-// beyond the best t.  It reproduces the reference walk's winner:
+// Walk of the library's own tree over the same triangles (rb_bvh.cpp / rb_build.hip; the default for
+// multi-node meshes, RB_FLAG_REFERENCE_WALK selects the reference's walk instead): nearer child first, subtrees
+// skipped when missed or entered beyond the best t.  It reproduces the reference walk's winner
+// (shader.wgsl:282-392) bit for bit -- DESIGN.md section 4 has the full argument:
 //  * candidates are evaluated with the reference's isect_triangle, so t, u, v are the same bits;
 //  * equal t resolves by the triangle's rank in the reference's visit order;
-//  * the reference only tests a triangle if every node from the root to its leaf passes
-//    intersect_aabb: an improving candidate is accepted only after that chain has been
-//    re-checked with the reference's own slab arithmetic on the reference's boxes;
-//  * boxes are inflated by a margin so rounding cannot cull a triangle the reference would hit.
-// Not a proof (an ill-conditioned Moller-Trumbore hit far outside its triangle could be missed),
-// which is why it is opt-in; the tests compare it bit for bit with the reference walk.
-// The walk is written as a resumable object so that the same steps serve the per-segment kernels
-// (intersect_bvh_fast below: run to completion) and the stepped kernel (k_trace_fast: lanes that
-// finish are shaded and refilled while the others keep walking).
-#ifndef RB_FAST_NODE_S
-#define RB_FAST_NODE_S 1
-#endif
+//  * the reference only tests a triangle if every node from the root to its leaf passes intersect_aabb: an
+//    improving candidate is accepted only after that chain has been re-checked with the reference's own slab
+//    arithmetic on the reference's boxes;
+//  * a subtree is skipped only if the ray misses its box INFLATED BY A MARGIN THAT BOUNDS HOW FAR FROM ITS
+//    TRIANGLE THE REFERENCE'S f32 MOLLER-TRUMBORE CAN REPORT A HIT, for every triangle below the box and this
+//    ray (entry()); where no finite bound exists (a ray within rounding of a triangle's plane) the subtree is
+//    entered unconditionally.  So the reference's winner is always among the candidates.
+// The walk is a resumable object so that the same steps serve the per-segment kernels (intersect_bvh_fast
+// below: run to completion) and the stepped kernel (k_trace_fast: lanes that finish are shaded and refilled
+// while the others keep walking).
+//
+// Culling margin of a child box for the ray (o, d), |d| = 1 +- 4 ulp.  For a triangle k below the box with
+// L = max(|e1|, |e2|), N = |e1 x e2|, s = o - v0, and the reference's computed determinant a^ (accepted only
+// if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies (u = 2^-24, first order, all roundings
+// of shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract):
+//     dist_inf(X, box(triangle k)) <= 26 u (|s| + L) L^2 / |a_k|  +  7.5 u (|s| + 2 L)        [DESIGN.md, E1-E7]
+// as long as 5.42 u L^2 / |a^| <= 0.05 (else no bound is claimed and the box is entered).  |a_k| = N_k |cos(d,
+// n_k)|; every unit normal below the child lies within angle alpha of +-c (its cone), so with x = |d . c|
+//     |cos(d, n_k)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) =: cos(alpha) g      (when g > 0)
+// and L_k^2 / |a_k| <= (max_k L_k^2 / N_k) / (cos(alpha) g) = invk / g =: F.  |s| + 2 L <= Sp = (distance from o
+// to the box's farthest corner) + 2 (sum of the box's extents).  With 10 u Sp more for the rounding of the slab
+// test itself:
+//     margin = Sp (27 u F + 20 u)        if F <= 1.5e5,        +infinity otherwise.
+// c, tan(alpha), invk are stored per child, rounded outwards (FastCone + the node's two pad words).
+constexpr float kFastKF = 27.0f * 5.9604645e-8f * 1.01f;
+constexpr float kFastKS = 20.0f * 5.9604645e-8f * 1.01f;
 template <bool STATS>
 struct FastWalk {
     f3 o, d, inv;
-    float S;            // 0.01 * farthest the ray origin can be from any point of the mesh
+    float m_ref;        // shrink of a reference leaf box for the chain shortcut (reference_would_test)
     TriHit h;
     uint32_t best_rank;
     uint32_t cur;       // current child reference (leaf: bit 31)
@@ -261,14 +276,12 @@ struct FastWalk {
         h.slot = 0u;
         best_rank = 0xFFFFFFFFu;
         inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
-        // S: farthest the ray origin can be from any point of the mesh (>= |origin - v0| for every
-        // triangle); with RB_FAST_NODE_S the per-box bound of entry() is used instead.  A child's box is
-        // inflated by m + 0.01 * S * (largest |e1||e2| below it): how far from its triangle a
-        // Moller-Trumbore hit with |a| >= 4.2e-5 can be reported (see rb_bvh.cpp)
+        // farthest the ray origin can be from any point of the mesh: the rounding error of a slab test on any of
+        // the reference's boxes is below 8 ulp of that
         const f3 fb0 = ld3(p.fast_bmin), fb1 = ld3(p.fast_bmax);
         const float sx_ = fmaxf(fabsf(o.x - fb0.x), fabsf(o.x - fb1.x)), sy_ = fmaxf(fabsf(o.y - fb0.y), fabsf(o.y - fb1.y)),
                     sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
-        S = 0.01f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
+        m_ref = 1e-6f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_) + 1e-30f;
         cur = p.fast_root;
         sp = 0;
     }
@@ -299,20 +312,23 @@ struct FastWalk {
         return true;
     }
 
-    DEV bool entry(const KParams& p, v4f lo, v4f hi, float amax, float& tn) const {
-#if RB_FAST_NODE_S
-        // |s| = |origin - v0| of the triangles below this box is at most the distance to its farthest corner
+    // visit the child unless the ray misses its inflated box or enters it beyond the best t (comparisons are
+    // written so that a NaN means "visit").  This arithmetic only steers the walk: fused operations and the
+    // hardware's approximate sqrt / rcp are fine as long as every rounding is on the safe side.
+    DEV bool entry(v4f lo, v4f hi, v4f cone, float invk, float& tn) const {
         const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
         const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
-        // (|x| + |y| + |z| instead of the root: no sqrt, but the looser bound costs 3-8 %)
-        const float mm = p.fast_margin + (0.01001f * __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz)) * amax;
+        // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
+        const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz))) +
+                          2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+        // g <= x - tan(alpha) sqrt(1 - x^2) for the true x = |d^ . c|: x is known to 5e-7, 1 - x^2 to 1e-6
+        const float x = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
+        const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-x, x, 1.0f), 0.0f) + 2e-6f);
+        const float g = __builtin_fmaf(-cone.w, root, x - 5e-7f);
+        const float F = invk * (1.00001f * __builtin_amdgcn_rcpf(fmaxf(g, 1e-9f)));
+        const float mm = (F <= 1.5e5f) ? sp_ * __builtin_fmaf(kFastKF, F, kFastKS) : 1e30f;   // NaN -> 1e30
         const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
         const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
-#else
-        const float mm = p.fast_margin + S * amax;
-        const f3 t0 = (mk(lo.x - mm, lo.y - mm, lo.z - mm) - o) * inv;
-        const f3 t1 = (mk(hi.x + mm, hi.y + mm, hi.z + mm) - o) * inv;
-#endif
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
         return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
@@ -322,11 +338,13 @@ struct FastWalk {
     // Returns false when the walk is complete.
     DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
         const cf4p nodes = (cf4p)p.fast_nodes;
+        const cf4p cones = (cf4p)p.fast_cones;
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
+        const v4f cl = cones[cur * 2u], cr = cones[cur * 2u + 1u];
         if constexpr (STATS) tl.nodes++;
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
-        const bool hl = entry(p, l0, l1, r0.w, tl_), hr = entry(p, r0, r1, r1.w, tr_);
+        const bool hl = entry(l0, l1, cl, r0.w, tl_), hr = entry(r0, r1, cr, r1.w, tr_);
         if (hl && hr) {
             const bool left_first = !(tr_ < tl_);
             push(p, stack, stride, sp, left_first ? rref : lref);
@@ -348,11 +366,12 @@ struct FastWalk {
     DEV bool reference_would_test(const KParams& p, uint32_t leaf_node, Tally<STATS>& tl) const {
         const cf4p rnodes = (cf4p)p.nodes;
         const RB_CONST uint32_t* parent = cptr(p.ref_parent);
-        const float m = p.fast_margin;
-        // Shortcut: if the ray passes through the reference LEAF's box shrunk by m on every side
-        // (m is far above the rounding error of a slab test), it passes through the interior of
-        // every ancestor's box, so each of the reference's slab tests succeeds; only a ray that
-        // merely grazes the leaf box needs the exact walk up the chain.
+        const float m = m_ref;
+        // Shortcut: if the ray passes through the reference LEAF's box shrunk by m on every side (m = 1e-6 of
+        // the farthest the origin can be from the mesh: twice the rounding error of this slab test plus that of
+        // the reference's), it passes through the interior of every ancestor's box with room to spare, so each of
+        // the reference's slab tests succeeds; only a ray that merely grazes the leaf box needs the exact walk
+        // up the chain.
         {
             const v4f n0 = rnodes[leaf_node * 3u], n1 = rnodes[leaf_node * 3u + 1u];
             if constexpr (STATS) tl.nodes++;

@@ -13,13 +13,6 @@ namespace rb {
 
 constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (LDS)
 constexpr uint32_t kDefaultStripeRows = 16;
-#ifndef RB_FAST_SLAB_MARGIN
-#define RB_FAST_SLAB_MARGIN 2e-5f
-#endif
-// fast triangle walk: part of the box inflation that covers the rounding of the slab tests themselves,
-// as a fraction of the mesh diagonal: their error is a few 2^-24 (~2.4e-7) of the coordinates involved, so
-// 2e-5 leaves two orders of magnitude; 1e-4 cost 9 % on a million small triangles
-constexpr float kFastSlabMargin = RB_FAST_SLAB_MARGIN;
 
 // ---- rb_bvh.cpp
 void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_node>& nodes,
@@ -47,7 +40,7 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 // Walk mode of multi-node meshes when the caller's flags do not say: the library's own tree (true) or the
 // reference walk (false).  RB_FLAG_REFERENCE_WALK / RB_FLAG_FAST_BVH override it per engine.
 #ifndef RB_FAST_WALK_DEFAULT
-#define RB_FAST_WALK_DEFAULT 0
+#define RB_FAST_WALK_DEFAULT 1
 #endif
 constexpr bool kFastWalkByDefault = RB_FAST_WALK_DEFAULT != 0;
 constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the library's tree is built on the device by default

@@ -78,6 +78,7 @@ struct rb_engine {
     mutable std::string error;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // read-backs into page-locked caller memory
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;   // per launch chunk: begin, after-trace, end
     uint32_t ev_used = 0;
@@ -817,6 +818,16 @@ int read_slot_rgba(rb_engine* e, int slot, uint8_t* out) {
     const uint32_t sc = e->opt.shard_count > 1 ? e->opt.shard_count : 1;
     const size_t bytes = static_cast<size_t>(e->width) * 4 * (sc == 1 ? e->height : e->padded_rows);
     if (bytes == 0) return RB_OK;
+    // Page-locked destination (rb_host_alloc, or memory the caller registered with HIP): a DMA on the copy
+    // stream straight into it, behind the slot's event -- no staging, no host-side copy.
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->slot[slot].done, 0));
+        HIP_TRY(e, hipMemcpyAsync(out, e->slot[slot].rgba.ptr, bytes, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+        return RB_OK;
+    }
+    (void)hipGetLastError();  // an unregistered pointer makes the query fail: that is the ordinary case
     HIP_TRY(e, hipEventSynchronize(e->slot[slot].done));
     HIP_TRY(e, hipMemcpy(out, e->slot[slot].rgba.ptr, bytes, hipMemcpyDeviceToHost));
     return RB_OK;
@@ -987,6 +998,7 @@ rb_engine* create_single(const rb_config* cfg, const rb_options& opt) {
     };
     hipError_t st;
     if ((st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", st);
+    if ((st = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", st);
     if ((st = hipEventCreate(&e->ev_begin)) != hipSuccess) return bail("hipEventCreate", st);
     if ((st = hipEventCreate(&e->ev_end)) != hipSuccess) return bail("hipEventCreate", st);
     for (FrameSlot& s : e->slot)
@@ -1185,6 +1197,10 @@ void rb_destroy(rb_engine* e) {
     // every launch, copy and event record of this engine was queued on its one stream: when that has
     // drained nothing on the device refers to the buffers, events or communicator any more
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) {
+        (void)hipStreamSynchronize(e->copy_stream);
+        (void)hipStreamDestroy(e->copy_stream);
+    }
     rb::gather_destroy(e->net);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
@@ -1383,6 +1399,19 @@ int rb_read_accumulation(rb_engine* e, float* accum_out) {
     return RB_OK;
 }
 
+void* rb_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void rb_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int rb_device_rgba(rb_engine* e, void** d_ptr, size_t* bytes) {
     if (!e) return RB_ERR_NULL_ARGUMENT;
     std::lock_guard<std::mutex> lock(e->mu);
@@ -1508,6 +1537,10 @@ int rb_reset_stats(rb_engine* e) {
 }
 
 static int part_reset_stats(rb_engine* e) {
+    {   // a launch group whose events have not been read yet belongs to the period that ends here
+        const int rc = accumulate_timing(e);
+        if (rc) return rc;
+    }
     HIP_TRY(e, hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream));
     e->stats = rb_stats{};
     return RB_OK;

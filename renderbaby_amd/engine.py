@@ -373,6 +373,29 @@ class FrameIterator:
             yield self.next()
 
 
+class PinnedFrame:
+    """A page-locked RGBA8 frame buffer (rb_host_alloc) as a numpy array: read-backs into it are DMA copies."""
+
+    def __init__(self, width, height):
+        self._lib = load()
+        self._p = self._lib.rb_host_alloc(width * height * 4)
+        if not self._p:
+            raise MemoryError("rb_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * (width * height * 4)).from_address(self._p)).reshape(height, width, 4)
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.rb_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def device_name(device=-1):
     buf = C.create_string_buffer(256)
     rc = load().rb_device_name(device, buf, 256)

@@ -181,3 +181,63 @@ def test_single_device_group_needs_no_communicator():
     e = Engine.new(rc, devices=[0])
     assert np.array_equal(e.render(rc).pixels, _oracle.render(s)[2])
     e.close()
+
+
+def _graze_scene(seed, coarse):
+    """A mesh and an eye in the plane of one of its triangles (tools/fuzz_parity.py::graze)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(seed)
+    if coarse:   # a few hundred large triangles in every orientation: wide normal cones, huge L^2
+        tris = []
+        for _ in range(400):
+            c = rng.uniform(-6, 6, 3)
+            tris.append(tuple(tuple(map(float, c + rng.uniform(-4, 4, 3))) for _ in range(3)))
+        groups = [(scenes.material(**scenes.KHAKI), tris), (scenes.material(**scenes.LIGHT), scenes._light_quad())]
+        u = scenes.make_uniforms(48, 32, 2, 4, cam_pos=(0, 0, 9), cam_dir=(0, 0, -1), sky=(0.5, 0.7, 1.0))
+        sc = scenes._finish("coarse", u, np.zeros(0, abi.SPHERE), np.zeros(0, abi.POINT_LIGHT), groups)
+    else:        # the smooth terrain + blob of C3 at reduced size: narrow cones, small triangles
+        sc = scenes.mesh_scene(40, 40, 48, 32, 2, 4, seed=seed)
+    fz.graze(sc, rng)
+    return sc
+
+
+@pytest.mark.parametrize("coarse", [False, True], ids=["smooth-mesh", "coarse-soup"])
+@pytest.mark.parametrize("builder", ["host-sah", "device-ploc", "device-lbvh"])
+def test_own_tree_with_rays_in_the_plane_of_a_triangle(coarse, builder):
+    # the culling margin of the library's tree must cover hits the reference reports from a near-zero
+    # determinant (|a| down to 1e-6): eyes in the plane of a triangle, looking along it, 12 scenes each
+    kw = dict(host_bvh=True) if builder == "host-sah" else dict(device_bvh=True, device_lbvh=(builder == "device-lbvh"))
+    for seed in range(12):
+        sc = _graze_scene(100 + seed, coarse)
+        o_acc, _, o_rgba, o_st = _oracle.render(sc)
+        rc = RenderConfig.from_scene(sc)
+        e = Engine.new(rc, **kw)
+        f = e.render(rc)
+        acc, st = e.read_accumulation(), e.stats()
+        assert e.last_kernel_name() == "k_trace_fast"
+        e.close()
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (seed, coarse, builder)
+        assert np.array_equal(f.pixels, o_rgba) and st["segments"] == o_st["segments"], (seed, coarse, builder)
+
+
+def test_pinned_frame_buffers_receive_the_same_frames():
+    from renderbaby_amd.engine import PinnedFrame
+    s = scenes.feature_scene(64, 40, 5, 4)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc)
+    want = [f.pixels.copy() for f in e.frame_iterator(rc)]
+    pf = PinnedFrame(64, 40)
+    cfg, keep = RenderConfig.from_scene(s, create=False).to_c()
+    e._check(e._lib.rb_iter_begin(e._h, C.byref(cfg)))
+    del keep
+    for k in range(5):
+        e._check(e._lib.rb_iter_next(e._h, pf.array.ctypes.data))
+        assert np.array_equal(pf.array, want[k]), k
+    e._check(e._lib.rb_render(e._h, pf.array.ctypes.data))
+    assert np.array_equal(pf.array, want[-1])
+    e.close()
+    pf.free()

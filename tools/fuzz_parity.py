@@ -82,7 +82,36 @@ def random_scene(seed):
             m = scenes.material(diffuse=f(0, 1, 3), specular=f(0, 1, 3) * (rng.random() < 0.5), shininess=float(f(0, 1100)),
                                 emissive=f(0, 5, 3) * (rng.random() < 0.3), texture_index=0 if (use_tex and g == 0) else -1)
             groups.append((m, tris)); uv_groups.append(uvs)
-    return scenes._finish(f"fuzz{seed}", u, sp, lights, groups, uv_groups, tex)
+    sc = scenes._finish(f"fuzz{seed}", u, sp, lights, groups, uv_groups, tex)
+    if nt and rng.random() < 0.25:
+        graze(sc, rng)
+    return sc
+
+
+def graze(sc, rng):
+    """Adversarial camera for the culling margins of the library's own tree: the eye lies (almost) IN the plane
+    of one triangle and looks along it through a narrow pane, so every primary ray is within a fraction of a
+    degree of that plane -- the regime where the reference's f32 Moller-Trumbore determinant is tiny and its
+    reported hits can lie far from the triangle."""
+    t = sc.bvh_triangles[int(rng.integers(0, len(sc.bvh_triangles)))]
+    v0, e1, e2 = t["v0"].astype(np.float64), (t["v1"] - t["v0"]).astype(np.float64), (t["v2"] - t["v0"]).astype(np.float64)
+    n = np.cross(e1, e2)
+    if not np.linalg.norm(n) > 0:
+        return
+    n /= np.linalg.norm(n)
+    a, b = rng.uniform(-0.5, 1.5, 2)
+    inplane = e1 * rng.uniform(-1, 1) + e2 * rng.uniform(-1, 1)
+    if not np.linalg.norm(inplane) > 0:
+        return
+    inplane /= np.linalg.norm(inplane)
+    off = float(rng.choice([0.0, 1e-7, 1e-5, 1e-3])) * float(rng.choice([-1, 1]))
+    tilt = float(rng.choice([0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3]))
+    pos = v0 + a * e1 + b * e2 - inplane * rng.uniform(0.5, 8.0) + n * off
+    d = inplane + n * tilt * float(rng.choice([-1, 1]))
+    sc.uniforms["camera"]["pos"] = pos.astype(np.float32)
+    sc.uniforms["camera"]["dir"] = d.astype(np.float32)
+    sc.uniforms["camera"]["pane_distance"] = np.float32(rng.choice([30.0, 60.0, 99.0]))
+    sc.uniforms["camera"]["pane_width"] = np.float32(rng.choice([0.01, 0.5, 4.0]))
 
 
 def variants(scene):

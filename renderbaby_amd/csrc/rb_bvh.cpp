@@ -254,28 +254,34 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 // Culling must never lose a triangle the reference would report as hit, and the reference's f32
 // Moller-Trumbore can report a hit some distance away from the triangle: at most
 // 26 u (|s| + L) L^2 / |a| + ... (rb_device_intersect.hpp, FastWalk::entry).  The traversal
-// turns that into a per-ray margin for each child box from three per-child numbers made here, all rounded
-// outwards: the axis c and half-angle alpha of a cone that contains every triangle normal below the child
-// (either orientation), stored as c and tan(alpha), and invk = max_k (L_k^2 / N_k) / cos(alpha)
-// (L = longer of the two edges at v0, N = |e1 x e2|).  A child whose normals do not fit a cone of less than
-// ~89 degrees, or that holds a triangle with N = 0, gets invk = +inf: it is always entered.
+// needs three things per child, made here and rounded outwards:
+//   FA   = max_k (L_k^2 / N_k) / (0.95 c0)  (L = longer of the two edges at v0, N = |e1 x e2|, c0 = kFastGrazeCos):
+//          scales the margin that covers every hit with |cos(ray, normal)| >= c0; +inf (always enter) beyond 1.5e5
+//          or when a triangle below has N = 0;
+//   cone = {c cos(alpha), tan(alpha)}: every triangle normal below lies within alpha of +-c; all zeros when the
+//          normals do not fit a cone of less than ~89 degrees (then a near-degenerate hit is always possible);
+//   R    = the union of the REFERENCE leaf boxes of the triangles below: a near-degenerate hit can be anywhere,
+//          but the reference only tests a triangle whose leaf box the ray passes.
 namespace {
 struct ItemGeom {       // per triangle, in double from the f32 edges the kernels use (e1 = fl(v1 - v0), ...)
     double n[3];        // unit normal (zero vector if N == 0)
     double q;           // L^2 / N  (+inf if N == 0)
 };
 struct ChildCone {
-    float c[3], tan_a, invk;
+    float c[3], tan_a, fa;   // c = axis * cos(alpha)
 };
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct FBuilder {
     const std::vector<float>& bmn;   // per item: tight box min (3 floats)
     const std::vector<float>& bmx;
+    const std::vector<float>& rmn;   // per item: box of the reference leaf that holds it
+    const std::vector<float>& rmx;
     const std::vector<ItemGeom>& geo;
     std::vector<uint32_t>& items;    // permuted in place
     std::vector<SphereNode>& nodes;
     std::vector<FastCone>& cones;    // parallel to nodes
+    std::vector<FastRBox>& rboxes;   // parallel to nodes
     uint32_t limit;
     uint32_t max_depth = 0;
     uint32_t par_levels = 0;   // levels below this call that may still fork a thread
@@ -293,19 +299,36 @@ struct FBuilder {
             }
         }
     }
+    void rbounds(size_t first, size_t count, float mn[4], float mx[4]) const {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::numeric_limits<float>::infinity();
+            mx[a] = -std::numeric_limits<float>::infinity();
+        }
+        mn[3] = mx[3] = 0.0f;
+        for (size_t i = first; i < first + count; ++i) {
+            const uint32_t it = items[i];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], rmn[it * 3 + a]);
+                mx[a] = std::max(mx[a], rmx[it * 3 + a]);
+            }
+        }
+    }
     float centroid(uint32_t it, int a) const { return 0.5f * (bmn[it * 3 + a] + bmx[it * 3 + a]); }
     static float area(const float mn[3], const float mx[3]) {
         const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
         return (x < 0 || y < 0 || z < 0) ? 0.0f : 2.0f * (x * y + y * z + z * x);
     }
-    // cone of the (unoriented) normals of items [first, first + count), and their largest L^2 / N
+    // FA and the cone of the (unoriented) normals of items [first, first + count)
     ChildCone cone(size_t first, size_t count) const {
         ChildCone out{{0.0f, 0.0f, 0.0f}, 0.0f, kInf};
         double sum[3] = {0, 0, 0}, ref[3] = {0, 0, 0}, qmax = 0.0;
-        bool have_ref = false;
+        bool have_ref = false, all_normals = true;
         for (size_t i = first; i < first + count; ++i) {
             const ItemGeom& g = geo[items[i]];
-            if (!(g.q < std::numeric_limits<double>::infinity())) return out;   // a triangle without a normal
+            if (!(g.q < std::numeric_limits<double>::infinity())) {   // a triangle without a normal
+                all_normals = false;
+                continue;
+            }
             qmax = std::max(qmax, g.q);
             if (!have_ref) {
                 for (int a = 0; a < 3; ++a) ref[a] = g.n[a];
@@ -314,24 +337,25 @@ struct FBuilder {
             const double sgn = (g.n[0] * ref[0] + g.n[1] * ref[1] + g.n[2] * ref[2]) < 0.0 ? -1.0 : 1.0;
             for (int a = 0; a < 3; ++a) sum[a] += sgn * g.n[a];
         }
+        if (!all_normals || !have_ref) return out;   // FA = inf, no cone: always entered
+        const double fa = qmax / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5);   // 0.95: |a^| >= 0.95 |a| in the bound's range
+        out.fa = (fa <= 1.5e5) ? static_cast<float>(fa) : kInf;
         const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-        if (!have_ref || !(len > 1e-9)) return out;
-        double c[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
-        // the stored axis is the f32 rounding of c: measure the cone around THAT vector
-        float cf[3] = {static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2])};
-        const double cl = std::sqrt(double(cf[0]) * cf[0] + double(cf[1]) * cf[1] + double(cf[2]) * cf[2]);
+        if (!(len > 1e-9)) return out;
+        const double c[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
         double cos_a = 1.0;
         for (size_t i = first; i < first + count; ++i) {
             const ItemGeom& g = geo[items[i]];
-            cos_a = std::min(cos_a, std::fabs(g.n[0] * cf[0] + g.n[1] * cf[1] + g.n[2] * cf[2]) / cl);
+            cos_a = std::min(cos_a, std::fabs(g.n[0] * c[0] + g.n[1] * c[1] + g.n[2] * c[2]));
         }
-        cos_a = cos_a * (1.0 - 1e-6) - 1e-7;     // the kernels take |d . cf| for |d^ . c|: |cf| is within 1e-7 of 1
-        if (!(cos_a > 0.0175)) return out;       // wider than ~89 degrees: no useful bound
+        cos_a = cos_a * (1.0 - 1e-6) - 1e-7;
+        if (!(cos_a > 0.0175)) return out;       // wider than ~89 degrees: a near-degenerate hit is always possible
         const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
-        out.c[0] = cf[0]; out.c[1] = cf[1]; out.c[2] = cf[2];
+        // stored: c cos(alpha) (f32 rounding of each component moves the vector by < 1e-7: inside the walk's slack)
+        out.c[0] = static_cast<float>(c[0] * cos_a);
+        out.c[1] = static_cast<float>(c[1] * cos_a);
+        out.c[2] = static_cast<float>(c[2] * cos_a);
         out.tan_a = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
-        out.invk = static_cast<float>(qmax / (0.95 * cos_a) * (1.0 + 1e-5));   // 0.95: |a^| >= 0.95 |a| in the bound's range
-        if (!(out.invk < kInf)) out = ChildCone{{0.0f, 0.0f, 0.0f}, 0.0f, kInf};
         return out;
     }
 
@@ -423,22 +447,29 @@ struct FBuilder {
         const uint32_t me = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
         cones.emplace_back();
+        rboxes.emplace_back();
         SphereNode n;
+        FastRBox rb_;
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
+        rbounds(first, mid - first, rb_.lmin, rb_.lmax);
+        rbounds(mid, first + count - mid, rb_.rmin, rb_.rmax);
         const ChildCone cl = cone(first, mid - first), cr = cone(mid, first + count - mid);
         if (count >= kParallelCount && par_levels > 0u) {
             std::vector<SphereNode> lv, rv;
             std::vector<FastCone> lc, rc;
-            FBuilder lb{bmn, bmx, geo, items, lv, lc, limit, 0, par_levels - 1u};
-            FBuilder rb{bmn, bmx, geo, items, rv, rc, limit, 0, par_levels - 1u};
+            std::vector<FastRBox> lr, rr;
+            FBuilder lb{bmn, bmx, rmn, rmx, geo, items, lv, lc, lr, limit, 0, par_levels - 1u};
+            FBuilder rb{bmn, bmx, rmn, rmx, geo, items, rv, rc, rr, limit, 0, par_levels - 1u};
             auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
             uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
             uint32_t lref = fut.get();
             append_subtree(nodes, lv, lref);
             cones.insert(cones.end(), lc.begin(), lc.end());
+            rboxes.insert(rboxes.end(), lr.begin(), lr.end());
             append_subtree(nodes, rv, rref);
             cones.insert(cones.end(), rc.begin(), rc.end());
+            rboxes.insert(rboxes.end(), rr.begin(), rr.end());
             n.left = lref;
             n.right = rref;
             max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
@@ -446,14 +477,15 @@ struct FBuilder {
             n.left = build(first, mid - first, depth + 1);
             n.right = build(mid, first + count - mid, depth + 1);
         }
-        // the two pad words: invk of each child (scales the per-ray inflation of that child's box)
-        std::memcpy(&n._pad0, &cl.invk, 4);
-        std::memcpy(&n._pad1, &cr.invk, 4);
+        // the two pad words: FA of each child (scales the inflation of that child's box)
+        std::memcpy(&n._pad0, &cl.fa, 4);
+        std::memcpy(&n._pad1, &cr.fa, 4);
         nodes[me] = n;
         FastCone fc;
         fc.l[0] = cl.c[0]; fc.l[1] = cl.c[1]; fc.l[2] = cl.c[2]; fc.l[3] = cl.tan_a;
         fc.r[0] = cr.c[0]; fc.r[1] = cr.c[1]; fc.r[2] = cr.c[2]; fc.r[3] = cr.tan_a;
         cones[me] = fc;
+        rboxes[me] = rb_;
         return me;
     }
 };
@@ -499,7 +531,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     const std::vector<uint32_t> slots = std::move(out.slots);
     // ---- tight boxes, normals and L^2 / N per item; items are indices into `slots`
     const size_t n = slots.size();
-    std::vector<float> bmn(n * 3), bmx(n * 3);
+    std::vector<float> bmn(n * 3), bmx(n * 3), rmn(n * 3), rmx(n * 3);
     std::vector<ItemGeom> geo(n);
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
@@ -519,7 +551,10 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
             g.q = std::max(l1, l2) / nn * (1.0 + 1e-9);
         }
         geo[i] = g;
+        const rb_bvh_node& leaf = ref_nodes[out.slot_meta[static_cast<size_t>(slots[i]) * 2]];
         for (int a = 0; a < 3; ++a) {
+            rmn[i * 3 + a] = leaf.aabb_min[a];
+            rmx[i * 3 + a] = leaf.aabb_max[a];
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
             smn[a] = std::min(smn[a], bmn[i * 3 + a]);
@@ -531,7 +566,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     // up to 64 threads at the sixth level; RB_HOST_BUILD_SEQUENTIAL=1 (debug) builds on one thread -- the
     // tree is the same either way (tests/test_gpu_parity.py compares the walk's counters)
     const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
-    FBuilder fb{bmn, bmx, geo, items, out.nodes, out.cones, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
+    FBuilder fb{bmn, bmx, rmn, rmx, geo, items, out.nodes, out.cones, out.rboxes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
     out.slots.resize(n);

@@ -234,27 +234,38 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 //  * the reference only tests a triangle if every node from the root to its leaf passes intersect_aabb: an
 //    improving candidate is accepted only after that chain has been re-checked with the reference's own slab
 //    arithmetic on the reference's boxes;
-//  * a subtree is skipped only if the ray misses its box INFLATED BY A MARGIN THAT BOUNDS HOW FAR FROM ITS
-//    TRIANGLE THE REFERENCE'S f32 MOLLER-TRUMBORE CAN REPORT A HIT, for every triangle below the box and this
-//    ray (entry()); where no finite bound exists (a ray within rounding of a triangle's plane) the subtree is
-//    entered unconditionally.  So the reference's winner is always among the candidates.
+//  * a subtree is skipped only when NO triangle below it can be an accepted hit of the reference for this ray
+//    (entry()): neither one the reference's f32 Moller-Trumbore reports near its triangle (A), nor one it
+//    reports from a near-zero determinant, possibly far away (B).  So the reference's winner is always among
+//    the candidates.
 // The walk is a resumable object so that the same steps serve the per-segment kernels (intersect_bvh_fast
 // below: run to completion) and the stepped kernel (k_trace_fast: lanes that finish are shaded and refilled
 // while the others keep walking).
 //
-// Culling margin of a child box for the ray (o, d), |d| = 1 +- 4 ulp.  For a triangle k below the box with
-// L = max(|e1|, |e2|), N = |e1 x e2|, s = o - v0, and the reference's computed determinant a^ (accepted only
-// if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies (u = 2^-24, first order, all roundings
-// of shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract):
-//     dist_inf(X, box(triangle k)) <= 26 u (|s| + L) L^2 / |a_k|  +  7.5 u (|s| + 2 L)        [DESIGN.md, E1-E7]
-// as long as 5.42 u L^2 / |a^| <= 0.05 (else no bound is claimed and the box is entered).  |a_k| = N_k |cos(d,
-// n_k)|; every unit normal below the child lies within angle alpha of +-c (its cone), so with x = |d . c|
-//     |cos(d, n_k)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) =: cos(alpha) g      (when g > 0)
-// and L_k^2 / |a_k| <= (max_k L_k^2 / N_k) / (cos(alpha) g) = invk / g =: F.  |s| + 2 L <= Sp = (distance from o
-// to the box's farthest corner) + 2 (sum of the box's extents).  With 10 u Sp more for the rounding of the slab
-// test itself:
-//     margin = Sp (27 u F + 20 u)        if F <= 1.5e5,        +infinity otherwise.
-// c, tan(alpha), invk are stored per child, rounded outwards (FastCone + the node's two pad words).
+// When may a child box be skipped for the ray (o, d), |d| = 1 +- 4 ulp?  For a triangle k below it with
+// L = max(|e1|, |e2|), N = |e1 x e2|, s = o - v0, a = d . (e2 x e1) = N cos(d, n_k), and the reference's computed
+// determinant a^ (a hit is accepted only if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies
+// (u = 2^-24, first order, every rounding of shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract;
+// DESIGN.md section 4, E1-E7)
+//     dist_inf(X, box(triangle k)) <= 26 u (|s| + L) L^2 / |a_k|  +  7.5 u (|s| + 2 L)
+// as long as 5.42 u L^2 / |a^| <= 0.05.  Split the triangles below the child by c0 = kFastGrazeCos:
+//  (A) |cos(d, n_k)| >= c0.  Then L^2 / |a_k| <= (max_k L_k^2 / N_k) / c0, a per-child constant FA (stored with
+//      the 0.95 that bounds |a^| >= 0.95 |a|, +inf beyond 1.5e5 where no bound is claimed), and with
+//      |s| + 2 L <= Sp = (distance from o to the child box's farthest corner) + 2 (sum of its extents), plus 10 u Sp
+//      for the rounding of the slab test itself, X lies inside the child's box inflated by
+//          margin = Sp (27 u FA + 20 u),
+//      entered no later than t^: the usual slab test with that margin and the cull `entry > best t` are safe.
+//  (B) |cos(d, n_k)| < c0: the ray is within ~1.7 degrees of the triangle's plane and no useful bound on X
+//      exists.  But the reference tests a triangle only if the ray passes its REFERENCE leaf's box
+//      (shader.wgsl:318-327), whatever Moller-Trumbore then reports.  Every child also stores R, the union of
+//      the reference leaf boxes of its triangles: if the ray misses R (inflated by the slab test's own
+//      rounding), the reference tests none of them.  (B) can only apply if some normal below is within
+//      asin(c0) of perpendicular to d: every unit normal below lies within angle alpha of +-c (the child's
+//      cone), so |cos(d, n_k)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with x = |d . c|; if that lower
+//      bound is >= c0 there is no class-(B) triangle and R is not even fetched.
+// A child is entered iff (A) passes, or (B) is possible and the ray hits R.  The (B) path has no t-cull (a
+// near-degenerate hit's t^ is not tied to where the triangle is).  Per child: FA (the node's two pad words),
+// {c cos(alpha), tan(alpha)} (FastCone), R (FastRBox), all rounded outwards by the builders.
 constexpr float kFastKF = 27.0f * 5.9604645e-8f * 1.01f;
 constexpr float kFastKS = 20.0f * 5.9604645e-8f * 1.01f;
 template <bool STATS>
@@ -315,23 +326,34 @@ struct FastWalk {
     // visit the child unless the ray misses its inflated box or enters it beyond the best t (comparisons are
     // written so that a NaN means "visit").  This arithmetic only steers the walk: fused operations and the
     // hardware's approximate sqrt / rcp are fine as long as every rounding is on the safe side.
-    DEV bool entry(v4f lo, v4f hi, v4f cone, float invk, float& tn) const {
+    // `rbox`: the two float4 of this child's R in p.fast_rboxes.
+    DEV bool entry(v4f lo, v4f hi, v4f cone, float fa, cf4p rbox, float& tn) const {
+        // ---- (A)
         const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
         const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
         // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
         const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz))) +
                           2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
-        // g <= x - tan(alpha) sqrt(1 - x^2) for the true x = |d^ . c|: x is known to 5e-7, 1 - x^2 to 1e-6
-        const float x = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
-        const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-x, x, 1.0f), 0.0f) + 2e-6f);
-        const float g = __builtin_fmaf(-cone.w, root, x - 5e-7f);
-        const float F = invk * (1.00001f * __builtin_amdgcn_rcpf(fmaxf(g, 1e-9f)));
-        const float mm = (F <= 1.5e5f) ? sp_ * __builtin_fmaf(kFastKF, F, kFastKS) : 1e30f;   // NaN -> 1e30
+        const float mm = (fa <= 1.5e5f) ? sp_ * __builtin_fmaf(kFastKF, fa, kFastKS) : 1e30f;   // NaN -> 1e30
         const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
         const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
-        return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
+        if (!(tf < fmaxf(tn, 0.0f)) && !(tn > h.t)) return true;
+        // ---- (B) possible?  lower bound of |cos(d, n)| over the cone: cone.xyz = c cos(alpha), cone.w = tan(alpha);
+        // y = |d . c| cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2 (an invalid cone is all zeros: bound 0)
+        const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
+        const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
+        const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);
+        const float lb = __builtin_fmaf(-cone.w, root, y - 1e-6f);
+        if (lb >= kFastGrazeCos) return false;   // every triangle below is class (A), and (A) failed
+        const v4f r0 = rbox[0], r1 = rbox[1];
+        const f3 ra = mk(r0.x - m_ref, r0.y - m_ref, r0.z - m_ref) - o, rb = mk(r1.x + m_ref, r1.y + m_ref, r1.z + m_ref) - o;
+        const f3 u0 = ra * inv, u1 = rb * inv;
+        const float rn = fmaxf(fmaxf(fminf(u0.x, u1.x), fminf(u0.y, u1.y)), fminf(u0.z, u1.z));
+        const float rf = fminf(fminf(fmaxf(u0.x, u1.x), fmaxf(u0.y, u1.y)), fmaxf(u0.z, u1.z));
+        tn = rn;
+        return !(rf < fmaxf(rn, 0.0f));
     }
 
     // cur is an internal node: descend into the nearer child that is hit, remember the other.
@@ -339,12 +361,13 @@ struct FastWalk {
     DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
         const cf4p nodes = (cf4p)p.fast_nodes;
         const cf4p cones = (cf4p)p.fast_cones;
+        const cf4p rboxes = (cf4p)p.fast_rboxes + cur * 4u;
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
         const v4f cl = cones[cur * 2u], cr = cones[cur * 2u + 1u];
         if constexpr (STATS) tl.nodes++;
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
-        const bool hl = entry(l0, l1, cl, r0.w, tl_), hr = entry(r0, r1, cr, r1.w, tr_);
+        const bool hl = entry(l0, l1, cl, r0.w, rboxes, tl_), hr = entry(r0, r1, cr, r1.w, rboxes + 2, tr_);
         if (hl && hr) {
             const bool left_first = !(tr_ < tl_);
             push(p, stack, stride, sp, left_first ? rref : lref);

@@ -44,57 +44,12 @@ __device__ __forceinline__ float ord2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-// ---- normal cones (rb_device_intersect.hpp, FastWalk::entry; the host builder's counterpart is
-// FBuilder::cone in rb_bvh.cpp).  A cone is {unit axis, half-angle alpha in radians} and contains every triangle
-// normal below a cluster in either orientation; alpha >= kConeInvalid means "no useful cone".  Built bottom-up:
-// a triangle's cone is its normal with alpha = 1e-6 (the f32 normal is within 3e-7 rad), two cones merge into
-// the cone around the normalised sum of their (sign-aligned) axes that contains both, every rounding outwards.
-constexpr float kConeInvalid = 1.55f;
-__device__ __forceinline__ float angle_between(float ax, float ay, float az, float bx, float by, float bz) {
-    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-    return atan2f(sqrtf(cx * cx + cy * cy + cz * cz), ax * bx + ay * by + az * bz);   // accurate for small angles
-}
-__device__ __forceinline__ float4 merge_cones(float4 a, float4 b) {
-    const float4 bad = make_float4(0.0f, 0.0f, 0.0f, 4.0f);
-    if (!(a.w < kConeInvalid) || !(b.w < kConeInvalid)) return bad;
-    if (a.x * b.x + a.y * b.y + a.z * b.z < 0.0f) { b.x = -b.x; b.y = -b.y; b.z = -b.z; }
-    float sx = a.x + b.x, sy = a.y + b.y, sz = a.z + b.z;
-    const float len = sqrtf(sx * sx + sy * sy + sz * sz);
-    if (!(len > 1e-6f)) return bad;
-    sx /= len; sy /= len; sz /= len;
-    const float alpha = fmaxf(angle_between(sx, sy, sz, a.x, a.y, a.z) + a.w, angle_between(sx, sy, sz, b.x, b.y, b.z) + b.w) + 3e-6f;
-    if (!(alpha < kConeInvalid)) return bad;
-    return make_float4(sx, sy, sz, alpha);
-}
-// what the walk reads per child: {axis cos(alpha), tan(alpha)} and FA = q / (0.95 c0), q = largest L^2 / N below
-// (+inf = always enter: no finite bound, or beyond the range the bound is claimed for)
-__device__ __forceinline__ void encode_cone(float4 cone, float q, float out[4], uint32_t& fa_bits) {
-    const float inf = __builtin_inff();
-    float fa = inf;
-    out[0] = out[1] = out[2] = out[3] = 0.0f;
-    if (q < inf) {
-        fa = q / (0.95f * kFastGrazeCos) * (1.0f + 1e-4f);
-        if (!(fa <= 1.5e5f)) fa = inf;
-        if (cone.w < kConeInvalid) {
-            const float ca = cosf(cone.w) * (1.0f - 1e-5f) - 1e-6f;
-            if (ca > 0.0175f) {
-                out[0] = cone.x * ca; out[1] = cone.y * ca; out[2] = cone.z * ca;
-                out[3] = tanf(cone.w) * (1.0f + 1e-4f) + 1e-6f;
-            }
-        }
-    }
-    fa_bits = __float_as_uint(fa);
-}
-
 // bounds[0..2] mesh min, [3..5] mesh max, [6..8] centroid min, [9..11] centroid max (ordered uints)
 __global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __restrict__ tris,
                                                      const uint32_t* __restrict__ indices,
-                                                     const uint32_t* __restrict__ slots,
-                                                     const uint32_t* __restrict__ slot_meta,
-                                                     const rb_bvh_node* __restrict__ ref_nodes, uint32_t n,
+                                                     const uint32_t* __restrict__ slots, uint32_t n,
                                                      float4* __restrict__ pmin, float4* __restrict__ pmax,
-                                                     float4* __restrict__ pcone, float4* __restrict__ prmin,
-                                                     float4* __restrict__ prmax, uint32_t* bounds) {
+                                                     uint32_t* bounds) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const float inf = __builtin_inff();
     float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
@@ -111,22 +66,13 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __res
             mx[a] = fmaxf(t.v0[a], fmaxf(t.v1[a], t.v2[a]));
             cn[a] = cx[a] = 0.5f * (mn[a] + mx[a]);
         }
-        // as the host builder: unit normal and q = L^2 / N (L the longer edge at v0, N = |e1 x e2|), in double
+        // as the host builder: q = L^2 / N (L the longer edge at v0, N = |e1 x e2|); its largest value below a
+        // child scales that child's culling margin (FastWalk::entry).  N = 0: +inf (the child is always entered)
         const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
         const double nn = sqrt(nx * nx + ny * ny + nz * nz);
-        float q = inf;
-        float4 cone = make_float4(0.0f, 0.0f, 0.0f, 4.0f);
-        if (nn > 0.0 && nn < 1e300) {
-            q = static_cast<float>(fmax(l1, l2) / nn * 1.000001);
-            cone = make_float4(static_cast<float>(nx / nn), static_cast<float>(ny / nn), static_cast<float>(nz / nn), 1e-6f);
-        }
+        const float q = (nn > 0.0 && nn < 1e300) ? static_cast<float>(fmax(l1, l2) / nn * 1.000001) : inf;
         pmin[i] = make_float4(mn[0], mn[1], mn[2], q);
         pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
-        pcone[i] = cone;
-        // the reference leaf that holds this triangle: its box is what the reference's walk tests before the triangle
-        const rb_bvh_node leaf = ref_nodes[slot_meta[(size_t)slots[i] * 2u]];
-        prmin[i] = make_float4(leaf.aabb_min[0], leaf.aabb_min[1], leaf.aabb_min[2], 0.0f);
-        prmax[i] = make_float4(leaf.aabb_max[0], leaf.aabb_max[1], leaf.aabb_max[2], 0.0f);
     }
     for (int a = 0; a < 3; ++a) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -229,16 +175,22 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long
     if (i == 0) parent[0] = 0u;
 }
 
-// nmin[i] = {box min, largest |e1||e2| below}, nmax[i] = {box max, height as uint bits}.
+// FA of a child from the largest q below it (rb_device_intersect.hpp, FastWalk::entry): q / (0.95 c0), +inf
+// (always enter) when no finite bound exists or beyond the range the bound is claimed for
+__device__ __forceinline__ uint32_t fa_bits(float q) {
+    float fa = q / (0.95f * kFastGrazeCos) * (1.0f + 1e-4f);
+    if (!(fa <= 1.5e5f)) fa = __builtin_inff();
+    return __float_as_uint(fa);
+}
+
+// nmin[i] = {box min, largest q below}, nmax[i] = {box max, height as uint bits}.
 __global__ void __launch_bounds__(256) k_lbvh_refit(const uint32_t* __restrict__ items, uint32_t n,
                                                      const float4* __restrict__ pmin, const float4* __restrict__ pmax,
                                                      const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                      const uint32_t* __restrict__ range_size,
                                                      const uint32_t* __restrict__ parent,
                                                      const uint32_t* __restrict__ leaf_parent, uint32_t* flags,
-                                                     const float4* __restrict__ pcone, const float4* __restrict__ prmin,
-                                                     const float4* __restrict__ prmax, float4* nmin, float4* nmax,
-                                                     float4* ncone, float4* nrmin, float4* nrmax) {
+                                                     float4* nmin, float4* nmax) {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     if (pos >= n) return;
     uint32_t cur = leaf_parent[pos];
@@ -246,7 +198,7 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const uint32_t* __restrict__
         __threadfence();
         if (atomicAdd(&flags[cur], 1u) == 0u) return;  // the sibling subtree is not finished yet
         __threadfence();
-        float4 lo[2], hi[2], cn[2], rl[2], rh[2];
+        float4 lo[2], hi[2];
         uint32_t hgt[2];
         const uint32_t ch[2] = {left[cur], right[cur]};
         for (int k = 0; k < 2; ++k) {
@@ -254,22 +206,13 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const uint32_t* __restrict__
                 const uint32_t item = items[ch[k] & ~kLeafTag];
                 lo[k] = pmin[item];
                 hi[k] = pmax[item];
-                cn[k] = pcone[item];
-                rl[k] = prmin[item];
-                rh[k] = prmax[item];
                 hgt[k] = 0u;
             } else {
                 lo[k] = nmin[ch[k]];  // written by another CU: the fence above has invalidated L1
                 hi[k] = nmax[ch[k]];
-                cn[k] = ncone[ch[k]];
-                rl[k] = nrmin[ch[k]];
-                rh[k] = nrmax[ch[k]];
                 hgt[k] = __float_as_uint(hi[k].w);
             }
         }
-        ncone[cur] = merge_cones(cn[0], cn[1]);
-        nrmin[cur] = make_float4(fminf(rl[0].x, rl[1].x), fminf(rl[0].y, rl[1].y), fminf(rl[0].z, rl[1].z), 0.0f);
-        nrmax[cur] = make_float4(fmaxf(rh[0].x, rh[1].x), fmaxf(rh[0].y, rh[1].y), fmaxf(rh[0].z, rh[1].z), 0.0f);
         // a node over exactly two triangles is emitted as a leaf: it adds no level
         const uint32_t h = (range_size[cur] == 2u) ? 0u : (hgt[0] > hgt[1] ? hgt[0] : hgt[1]) + 1u;
         nmin[cur] = make_float4(fminf(lo[0].x, lo[1].x), fminf(lo[0].y, lo[1].y), fminf(lo[0].z, lo[1].z),
@@ -288,16 +231,12 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ 
                                                     const uint32_t* __restrict__ range_first,
                                                     const uint32_t* __restrict__ range_size,
                                                     const float4* __restrict__ nmin, const float4* __restrict__ nmax,
-                                                    const float4* __restrict__ pcone, const float4* __restrict__ ncone,
-                                                    const float4* __restrict__ prmin, const float4* __restrict__ prmax,
-                                                    const float4* __restrict__ nrmin, const float4* __restrict__ nrmax,
                                                     const uint32_t* __restrict__ bounds, SphereNode* __restrict__ nodes,
-                                                    FastCone* __restrict__ cones, FastRBox* __restrict__ rboxes,
                                                     uint32_t* __restrict__ fast_slots, DeviceTreeInfo* info) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) fast_slots[i] = slots[items[i]];
     if (i + 1u < n) {
-        float4 o[4], cn[2], rr[4];
+        float4 o[4];
         uint32_t ref[2];
         const uint32_t ch[2] = {left[i], right[i]};
         for (int k = 0; k < 2; ++k) {
@@ -306,35 +245,19 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ 
                 const uint32_t item = items[pos];
                 o[2 * k] = pmin[item];
                 o[2 * k + 1] = pmax[item];
-                cn[k] = pcone[item];
-                rr[2 * k] = prmin[item];
-                rr[2 * k + 1] = prmax[item];
                 ref[k] = kLeafTag | pos;
             } else {
                 o[2 * k] = nmin[ch[k]];
                 o[2 * k + 1] = nmax[ch[k]];
-                cn[k] = ncone[ch[k]];
-                rr[2 * k] = nrmin[ch[k]];
-                rr[2 * k + 1] = nrmax[ch[k]];
                 ref[k] = (range_size[ch[k]] == 2u) ? (kLeafTag | (1u << 28) | range_first[ch[k]]) : ch[k];
             }
         }
         SphereNode nd;
-        FastCone fc;
-        encode_cone(cn[0], o[0].w, fc.l, nd._pad0);
-        encode_cone(cn[1], o[2].w, fc.r, nd._pad1);
         nd.lmin[0] = o[0].x; nd.lmin[1] = o[0].y; nd.lmin[2] = o[0].z; nd.left = ref[0];
         nd.lmax[0] = o[1].x; nd.lmax[1] = o[1].y; nd.lmax[2] = o[1].z; nd.right = ref[1];
-        nd.rmin[0] = o[2].x; nd.rmin[1] = o[2].y; nd.rmin[2] = o[2].z;
-        nd.rmax[0] = o[3].x; nd.rmax[1] = o[3].y; nd.rmax[2] = o[3].z;
+        nd.rmin[0] = o[2].x; nd.rmin[1] = o[2].y; nd.rmin[2] = o[2].z; nd._pad0 = fa_bits(o[0].w);
+        nd.rmax[0] = o[3].x; nd.rmax[1] = o[3].y; nd.rmax[2] = o[3].z; nd._pad1 = fa_bits(o[2].w);
         nodes[i] = nd;
-        cones[i] = fc;
-        FastRBox rb_;
-        rb_.lmin[0] = rr[0].x; rb_.lmin[1] = rr[0].y; rb_.lmin[2] = rr[0].z; rb_.lmin[3] = 0.0f;
-        rb_.lmax[0] = rr[1].x; rb_.lmax[1] = rr[1].y; rb_.lmax[2] = rr[1].z; rb_.lmax[3] = 0.0f;
-        rb_.rmin[0] = rr[2].x; rb_.rmin[1] = rr[2].y; rb_.rmin[2] = rr[2].z; rb_.rmin[3] = 0.0f;
-        rb_.rmax[0] = rr[3].x; rb_.rmax[1] = rr[3].y; rb_.rmax[2] = rr[3].z; rb_.rmax[3] = 0.0f;
-        rboxes[i] = rb_;
     }
     if (i == 0u) {
         const float4 r0 = nmin[0], r1 = nmax[0];
@@ -362,20 +285,16 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ 
 constexpr int kPlocRadius = RB_PLOC_RADIUS;
 
 struct PlocClusters {
-    float4* lo;      // box min, largest L^2 / N below
+    float4* lo;      // box min, largest q = L^2 / N below
     float4* hi;      // box max, height (uint bits)
-    float4* cone;    // cone of the normals below
-    float4* rlo;     // union of the reference leaf boxes of the triangles below
-    float4* rhi;
     uint32_t* ref;   // child reference a parent would store
     uint32_t* run;   // single triangle: its position in the Morton order; otherwise ~0
 };
 
 __global__ void __launch_bounds__(256) k_ploc_init(const uint32_t* __restrict__ items, const uint32_t* __restrict__ slots,
                                                     uint32_t n, const float4* __restrict__ pmin,
-                                                    const float4* __restrict__ pmax, const float4* __restrict__ pcone,
-                                                    const float4* __restrict__ prmin, const float4* __restrict__ prmax,
-                                                    PlocClusters c, uint32_t* __restrict__ fast_slots, uint32_t* counters) {
+                                                    const float4* __restrict__ pmax, PlocClusters c,
+                                                    uint32_t* __restrict__ fast_slots, uint32_t* counters) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0u) {
         counters[0] = n;   // live clusters
@@ -386,9 +305,6 @@ __global__ void __launch_bounds__(256) k_ploc_init(const uint32_t* __restrict__ 
     const float4 a = pmin[item], b = pmax[item];
     c.lo[i] = a;
     c.hi[i] = make_float4(b.x, b.y, b.z, __uint_as_float(0u));
-    c.cone[i] = pcone[item];
-    c.rlo[i] = prmin[item];
-    c.rhi[i] = prmax[item];
     c.ref[i] = kLeafTag | i;
     c.run[i] = i;
     fast_slots[i] = slots[item];
@@ -425,8 +341,7 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const uint32_t* __restrict__ co
 
 __global__ void __launch_bounds__(256) k_ploc_merge(uint32_t* counters, uint32_t n, PlocClusters c,
                                                      const uint32_t* __restrict__ nn, uint32_t* __restrict__ keep,
-                                                     SphereNode* __restrict__ nodes, FastCone* __restrict__ cones,
-                                                     FastRBox* __restrict__ rboxes) {
+                                                     SphereNode* __restrict__ nodes) {
     const uint32_t count = counters[0];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -448,8 +363,6 @@ __global__ void __launch_bounds__(256) k_ploc_merge(uint32_t* counters, uint32_t
     const uint32_t ra = c.ref[i], rb = c.ref[j];
     const uint32_t pa = c.run[i], pb = c.run[j];
     const uint32_t ha = __float_as_uint(a1.w), hb = __float_as_uint(b1.w);
-    const float4 ca = c.cone[i], cb = c.cone[j];
-    const float4 ral = c.rlo[i], rah = c.rhi[i], rbl = c.rlo[j], rbh = c.rhi[j];
     uint32_t ref, h;
     if (pa != 0xFFFFFFFFu && pb == pa + 1u) {
         ref = kLeafTag | (1u << 28) | pa;  // neighbours in the triangle order: one two-triangle leaf
@@ -457,29 +370,16 @@ __global__ void __launch_bounds__(256) k_ploc_merge(uint32_t* counters, uint32_t
     } else {
         const uint32_t id = atomicAdd(&counters[1], 1u);
         SphereNode nd;
-        FastCone fc;
-        encode_cone(ca, a0.w, fc.l, nd._pad0);
-        encode_cone(cb, b0.w, fc.r, nd._pad1);
         nd.lmin[0] = a0.x; nd.lmin[1] = a0.y; nd.lmin[2] = a0.z; nd.left = ra;
         nd.lmax[0] = a1.x; nd.lmax[1] = a1.y; nd.lmax[2] = a1.z; nd.right = rb;
-        nd.rmin[0] = b0.x; nd.rmin[1] = b0.y; nd.rmin[2] = b0.z;
-        nd.rmax[0] = b1.x; nd.rmax[1] = b1.y; nd.rmax[2] = b1.z;
+        nd.rmin[0] = b0.x; nd.rmin[1] = b0.y; nd.rmin[2] = b0.z; nd._pad0 = fa_bits(a0.w);
+        nd.rmax[0] = b1.x; nd.rmax[1] = b1.y; nd.rmax[2] = b1.z; nd._pad1 = fa_bits(b0.w);
         nodes[id] = nd;
-        cones[id] = fc;
-        FastRBox rb_;
-        rb_.lmin[0] = ral.x; rb_.lmin[1] = ral.y; rb_.lmin[2] = ral.z; rb_.lmin[3] = 0.0f;
-        rb_.lmax[0] = rah.x; rb_.lmax[1] = rah.y; rb_.lmax[2] = rah.z; rb_.lmax[3] = 0.0f;
-        rb_.rmin[0] = rbl.x; rb_.rmin[1] = rbl.y; rb_.rmin[2] = rbl.z; rb_.rmin[3] = 0.0f;
-        rb_.rmax[0] = rbh.x; rb_.rmax[1] = rbh.y; rb_.rmax[2] = rbh.z; rb_.rmax[3] = 0.0f;
-        rboxes[id] = rb_;
         ref = id;
         h = (ha > hb ? ha : hb) + 1u;
     }
     c.lo[i] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
     c.hi[i] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), __uint_as_float(h));
-    c.cone[i] = merge_cones(ca, cb);
-    c.rlo[i] = make_float4(fminf(ral.x, rbl.x), fminf(ral.y, rbl.y), fminf(ral.z, rbl.z), 0.0f);
-    c.rhi[i] = make_float4(fmaxf(rah.x, rbh.x), fmaxf(rah.y, rbh.y), fmaxf(rah.z, rbh.z), 0.0f);
     c.ref[i] = ref;
     c.run[i] = 0xFFFFFFFFu;
     keep[i] = 1u;
@@ -494,9 +394,6 @@ __global__ void __launch_bounds__(256) k_ploc_scatter(uint32_t* counters, uint32
         const uint32_t d = pos[i];
         to.lo[d] = from.lo[i];
         to.hi[d] = from.hi[i];
-        to.cone[d] = from.cone[i];
-        to.rlo[d] = from.rlo[i];
-        to.rhi[d] = from.rhi[i];
         to.ref[d] = from.ref[i];
         to.run[d] = from.run[i];
     }
@@ -524,8 +421,7 @@ inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
 
 // All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          const uint32_t* slot_meta, const rb_bvh_node* ref_nodes, SphereNode* nodes_out, FastCone* cones_out,
-                          FastRBox* rboxes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream_,
+                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream_,
                           bool plain_lbvh) {
     if (n < 2u || n >= (1u << 28)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -541,8 +437,6 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     const size_t o_keys_in = carve(sizeof(key_t) * n), o_keys = carve(sizeof(key_t) * n);
     const size_t o_items_in = carve(4u * n), o_items = carve(4u * n);
     const size_t o_pmin = carve(16u * n), o_pmax = carve(16u * n), o_nmin = carve(16u * n), o_nmax = carve(16u * n);
-    const size_t o_pcone = carve(16u * n), o_ncone = carve(16u * n);
-    const size_t o_prmin = carve(16u * n), o_prmax = carve(16u * n), o_nrmin = carve(16u * n), o_nrmax = carve(16u * n);
     const size_t o_left = carve(4u * n), o_right = carve(4u * n), o_first = carve(4u * n), o_size = carve(4u * n);
     const size_t o_parent = carve(4u * n), o_leafpar = carve(4u * n), o_flags = carve(4u * n);
     const size_t o_bounds = carve(64), o_info = carve(sizeof(DeviceTreeInfo)), o_sort = carve(sort_bytes);
@@ -554,8 +448,6 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
         if (e != hipSuccess) return static_cast<int>(e);
     }
     const size_t o_blo = carve(plain_lbvh ? 0 : 16u * n), o_bhi = carve(plain_lbvh ? 0 : 16u * n);
-    const size_t o_bcone = carve(plain_lbvh ? 0 : 16u * n);
-    const size_t o_brlo = carve(plain_lbvh ? 0 : 16u * n), o_brhi = carve(plain_lbvh ? 0 : 16u * n);
     const size_t o_aref = carve(plain_lbvh ? 0 : 4u * n), o_bref = carve(plain_lbvh ? 0 : 4u * n);
     const size_t o_arun = carve(plain_lbvh ? 0 : 4u * n), o_brun = carve(plain_lbvh ? 0 : 4u * n);
     const size_t o_scan = carve(scan_bytes), o_counters = carve(64);
@@ -571,12 +463,6 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     float4* pmax = reinterpret_cast<float4*>(at(o_pmax));
     float4* nmin = reinterpret_cast<float4*>(at(o_nmin));
     float4* nmax = reinterpret_cast<float4*>(at(o_nmax));
-    float4* pcone = reinterpret_cast<float4*>(at(o_pcone));
-    float4* ncone = reinterpret_cast<float4*>(at(o_ncone));
-    float4* prmin = reinterpret_cast<float4*>(at(o_prmin));
-    float4* prmax = reinterpret_cast<float4*>(at(o_prmax));
-    float4* nrmin = reinterpret_cast<float4*>(at(o_nrmin));
-    float4* nrmax = reinterpret_cast<float4*>(at(o_nrmax));
     uint32_t* left = reinterpret_cast<uint32_t*>(at(o_left));
     uint32_t* right = reinterpret_cast<uint32_t*>(at(o_right));
     uint32_t* rfirst = reinterpret_cast<uint32_t*>(at(o_first));
@@ -599,8 +485,7 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     if (e != hipSuccess) return done(e);
     e = hipMemsetAsync(flags, 0, 4u * n, stream);
     if (e != hipSuccess) return done(e);
-    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, slot_meta, ref_nodes, n, pmin, pmax, pcone,
-                       prmin, prmax, bounds);
+    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, n, pmin, pmax, bounds);
     hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, stream, pmin, pmax, n, bounds, keys_in, items_in);
     e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_in, keys, items_in, items, n, 0, 63, stream);
     if (e != hipSuccess) return done(e);
@@ -608,19 +493,15 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
         // nn / keep / pos reuse the LBVH link arrays
         uint32_t *nn = left, *keep = right, *pos = rfirst;
         uint32_t* counters = reinterpret_cast<uint32_t*>(at(o_counters));
-        PlocClusters A{nmin, nmax, ncone, nrmin, nrmax, reinterpret_cast<uint32_t*>(at(o_aref)),
-                       reinterpret_cast<uint32_t*>(at(o_arun))};
+        PlocClusters A{nmin, nmax, reinterpret_cast<uint32_t*>(at(o_aref)), reinterpret_cast<uint32_t*>(at(o_arun))};
         PlocClusters B{reinterpret_cast<float4*>(at(o_blo)), reinterpret_cast<float4*>(at(o_bhi)),
-                       reinterpret_cast<float4*>(at(o_bcone)), reinterpret_cast<float4*>(at(o_brlo)),
-                       reinterpret_cast<float4*>(at(o_brhi)), reinterpret_cast<uint32_t*>(at(o_bref)),
-                       reinterpret_cast<uint32_t*>(at(o_brun))};
-        hipLaunchKernelGGL(k_ploc_init, grid, block, 0, stream, items, slots, n, pmin, pmax, pcone, prmin, prmax, A,
-                           fast_slots_out, counters);
+                       reinterpret_cast<uint32_t*>(at(o_bref)), reinterpret_cast<uint32_t*>(at(o_brun))};
+        hipLaunchKernelGGL(k_ploc_init, grid, block, 0, stream, items, slots, n, pmin, pmax, A, fast_slots_out, counters);
         uint32_t live = n;
         for (int round = 0; live > 1u && round < 4096; ++round) {
             const dim3 g((live + 255u) / 256u);  // `live` is an upper bound of the device-side count
             hipLaunchKernelGGL(k_ploc_nn, g, block, 0, stream, counters, A, nn);
-            hipLaunchKernelGGL(k_ploc_merge, g, block, 0, stream, counters, live, A, nn, keep, nodes_out, cones_out, rboxes_out);
+            hipLaunchKernelGGL(k_ploc_merge, g, block, 0, stream, counters, live, A, nn, keep, nodes_out);
             e = rocprim::exclusive_scan(at(o_scan), scan_bytes, keep, pos, 0u, live, rocprim::plus<uint32_t>(), stream);
             if (e != hipSuccess) return done(e);
             hipLaunchKernelGGL(k_ploc_scatter, g, block, 0, stream, counters, live, A, B, keep, pos);
@@ -647,10 +528,9 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     }
     hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, stream, keys, n, left, right, rfirst, rsize, parent, leafpar);
     hipLaunchKernelGGL(k_lbvh_refit, grid, block, 0, stream, items, n, pmin, pmax, left, right, rsize, parent, leafpar,
-                       flags, pcone, prmin, prmax, nmin, nmax, ncone, nrmin, nrmax);
+                       flags, nmin, nmax);
     hipLaunchKernelGGL(k_lbvh_emit, grid, block, 0, stream, items, n, slots, pmin, pmax, left, right, rfirst, rsize,
-                       nmin, nmax, pcone, ncone, prmin, prmax, nrmin, nrmax, bounds, nodes_out, cones_out, rboxes_out,
-                       fast_slots_out, d_info);
+                       nmin, nmax, bounds, nodes_out, fast_slots_out, d_info);
     e = hipGetLastError();
     if (e != hipSuccess) return done(e);
     e = hipStreamSynchronize(stream);

@@ -13,6 +13,7 @@
 #include "rb_internal.hpp"
 
 #include <algorithm>
+#include <array>
 #include <future>
 #include <cmath>
 #include <cstdlib>
@@ -253,35 +254,24 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 //
 // Culling must never lose a triangle the reference would report as hit, and the reference's f32
 // Moller-Trumbore can report a hit some distance away from the triangle: at most
-// 26 u (|s| + L) L^2 / |a| + ... (rb_device_intersect.hpp, FastWalk::entry).  The traversal
-// needs three things per child, made here and rounded outwards:
-//   FA   = max_k (L_k^2 / N_k) / (0.95 c0)  (L = longer of the two edges at v0, N = |e1 x e2|, c0 = kFastGrazeCos):
-//          scales the margin that covers every hit with |cos(ray, normal)| >= c0; +inf (always enter) beyond 1.5e5
-//          or when a triangle below has N = 0;
-//   cone = {c cos(alpha), tan(alpha)}: every triangle normal below lies within alpha of +-c; all zeros when the
-//          normals do not fit a cone of less than ~89 degrees (then a near-degenerate hit is always possible);
-//   R    = the union of the REFERENCE leaf boxes of the triangles below: a near-degenerate hit can be anywhere,
-//          but the reference only tests a triangle whose leaf box the ray passes.
+// 26 u (|s| + L) L^2 / |a| + ... (rb_device_intersect.hpp, FastWalk::entry).  Two things
+// are made here for that, rounded outwards:
+//   per child of the library's tree  FA = max_k (L_k^2 / N_k) / (0.95 c0)  (L = longer of the two edges at v0,
+//       N = |e1 x e2|, c0 = kFastGrazeCos): scales the margin that covers every hit with |cos(ray, normal)| >= c0;
+//       +inf (always enter) beyond 1.5e5 or when a triangle below has N = 0;
+//   per node of the REFERENCE tree  a cone {c cos(alpha), tan(alpha)} that contains every triangle normal below
+//       it (either orientation): the hits with |cos| < c0 -- a ray within ~1.7 degrees of the triangle's plane,
+//       where no useful bound exists -- are found by a second walk over the reference's own tree that only
+//       enters nodes whose cone admits such a triangle (FastWalk::graze_pass).
 namespace {
-struct ItemGeom {       // per triangle, in double from the f32 edges the kernels use (e1 = fl(v1 - v0), ...)
-    double n[3];        // unit normal (zero vector if N == 0)
-    double q;           // L^2 / N  (+inf if N == 0)
-};
-struct ChildCone {
-    float c[3], tan_a, fa;   // c = axis * cos(alpha)
-};
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct FBuilder {
     const std::vector<float>& bmn;   // per item: tight box min (3 floats)
     const std::vector<float>& bmx;
-    const std::vector<float>& rmn;   // per item: box of the reference leaf that holds it
-    const std::vector<float>& rmx;
-    const std::vector<ItemGeom>& geo;
+    const std::vector<float>& q;     // per item: L^2 / N (+inf if N == 0)
     std::vector<uint32_t>& items;    // permuted in place
     std::vector<SphereNode>& nodes;
-    std::vector<FastCone>& cones;    // parallel to nodes
-    std::vector<FastRBox>& rboxes;   // parallel to nodes
     uint32_t limit;
     uint32_t max_depth = 0;
     uint32_t par_levels = 0;   // levels below this call that may still fork a thread
@@ -299,64 +289,16 @@ struct FBuilder {
             }
         }
     }
-    void rbounds(size_t first, size_t count, float mn[4], float mx[4]) const {
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = std::numeric_limits<float>::infinity();
-            mx[a] = -std::numeric_limits<float>::infinity();
-        }
-        mn[3] = mx[3] = 0.0f;
-        for (size_t i = first; i < first + count; ++i) {
-            const uint32_t it = items[i];
-            for (int a = 0; a < 3; ++a) {
-                mn[a] = std::min(mn[a], rmn[it * 3 + a]);
-                mx[a] = std::max(mx[a], rmx[it * 3 + a]);
-            }
-        }
-    }
     float centroid(uint32_t it, int a) const { return 0.5f * (bmn[it * 3 + a] + bmx[it * 3 + a]); }
+    float fa(size_t first, size_t count) const {
+        float m = 0.0f;
+        for (size_t i = first; i < first + count; ++i) m = std::max(m, q[items[i]]);
+        const double f = double(m) / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5);   // 0.95: |a^| >= 0.95 |a| in the bound's range
+        return (f <= 1.5e5) ? static_cast<float>(f) : kInf;
+    }
     static float area(const float mn[3], const float mx[3]) {
         const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
         return (x < 0 || y < 0 || z < 0) ? 0.0f : 2.0f * (x * y + y * z + z * x);
-    }
-    // FA and the cone of the (unoriented) normals of items [first, first + count)
-    ChildCone cone(size_t first, size_t count) const {
-        ChildCone out{{0.0f, 0.0f, 0.0f}, 0.0f, kInf};
-        double sum[3] = {0, 0, 0}, ref[3] = {0, 0, 0}, qmax = 0.0;
-        bool have_ref = false, all_normals = true;
-        for (size_t i = first; i < first + count; ++i) {
-            const ItemGeom& g = geo[items[i]];
-            if (!(g.q < std::numeric_limits<double>::infinity())) {   // a triangle without a normal
-                all_normals = false;
-                continue;
-            }
-            qmax = std::max(qmax, g.q);
-            if (!have_ref) {
-                for (int a = 0; a < 3; ++a) ref[a] = g.n[a];
-                have_ref = true;
-            }
-            const double sgn = (g.n[0] * ref[0] + g.n[1] * ref[1] + g.n[2] * ref[2]) < 0.0 ? -1.0 : 1.0;
-            for (int a = 0; a < 3; ++a) sum[a] += sgn * g.n[a];
-        }
-        if (!all_normals || !have_ref) return out;   // FA = inf, no cone: always entered
-        const double fa = qmax / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5);   // 0.95: |a^| >= 0.95 |a| in the bound's range
-        out.fa = (fa <= 1.5e5) ? static_cast<float>(fa) : kInf;
-        const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-        if (!(len > 1e-9)) return out;
-        const double c[3] = {sum[0] / len, sum[1] / len, sum[2] / len};
-        double cos_a = 1.0;
-        for (size_t i = first; i < first + count; ++i) {
-            const ItemGeom& g = geo[items[i]];
-            cos_a = std::min(cos_a, std::fabs(g.n[0] * c[0] + g.n[1] * c[1] + g.n[2] * c[2]));
-        }
-        cos_a = cos_a * (1.0 - 1e-6) - 1e-7;
-        if (!(cos_a > 0.0175)) return out;       // wider than ~89 degrees: a near-degenerate hit is always possible
-        const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
-        // stored: c cos(alpha) (f32 rounding of each component moves the vector by < 1e-7: inside the walk's slack)
-        out.c[0] = static_cast<float>(c[0] * cos_a);
-        out.c[1] = static_cast<float>(c[1] * cos_a);
-        out.c[2] = static_cast<float>(c[2] * cos_a);
-        out.tan_a = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
-        return out;
     }
 
     uint32_t build(size_t first, size_t count, uint32_t depth) {
@@ -446,30 +388,18 @@ struct FBuilder {
         }
         const uint32_t me = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
-        cones.emplace_back();
-        rboxes.emplace_back();
         SphereNode n;
-        FastRBox rb_;
         bounds(first, mid - first, n.lmin, n.lmax);
         bounds(mid, first + count - mid, n.rmin, n.rmax);
-        rbounds(first, mid - first, rb_.lmin, rb_.lmax);
-        rbounds(mid, first + count - mid, rb_.rmin, rb_.rmax);
-        const ChildCone cl = cone(first, mid - first), cr = cone(mid, first + count - mid);
         if (count >= kParallelCount && par_levels > 0u) {
             std::vector<SphereNode> lv, rv;
-            std::vector<FastCone> lc, rc;
-            std::vector<FastRBox> lr, rr;
-            FBuilder lb{bmn, bmx, rmn, rmx, geo, items, lv, lc, lr, limit, 0, par_levels - 1u};
-            FBuilder rb{bmn, bmx, rmn, rmx, geo, items, rv, rc, rr, limit, 0, par_levels - 1u};
+            FBuilder lb{bmn, bmx, q, items, lv, limit, 0, par_levels - 1u};
+            FBuilder rb{bmn, bmx, q, items, rv, limit, 0, par_levels - 1u};
             auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
             uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
             uint32_t lref = fut.get();
             append_subtree(nodes, lv, lref);
-            cones.insert(cones.end(), lc.begin(), lc.end());
-            rboxes.insert(rboxes.end(), lr.begin(), lr.end());
             append_subtree(nodes, rv, rref);
-            cones.insert(cones.end(), rc.begin(), rc.end());
-            rboxes.insert(rboxes.end(), rr.begin(), rr.end());
             n.left = lref;
             n.right = rref;
             max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
@@ -478,39 +408,61 @@ struct FBuilder {
             n.right = build(mid, first + count - mid, depth + 1);
         }
         // the two pad words: FA of each child (scales the inflation of that child's box)
-        std::memcpy(&n._pad0, &cl.fa, 4);
-        std::memcpy(&n._pad1, &cr.fa, 4);
+        const float al = fa(first, mid - first), ar = fa(mid, first + count - mid);
+        std::memcpy(&n._pad0, &al, 4);
+        std::memcpy(&n._pad1, &ar, 4);
         nodes[me] = n;
-        FastCone fc;
-        fc.l[0] = cl.c[0]; fc.l[1] = cl.c[1]; fc.l[2] = cl.c[2]; fc.l[3] = cl.tan_a;
-        fc.r[0] = cr.c[0]; fc.r[1] = cr.c[1]; fc.r[2] = cr.c[2]; fc.r[3] = cr.tan_a;
-        cones[me] = fc;
-        rboxes[me] = rb_;
         return me;
     }
 };
 }  // namespace
 
-bool fast_bvh_prepare(uint32_t tri_count, const uint32_t* indices, uint32_t index_len, const rb_bvh_node* ref_nodes,
-                      uint32_t node_count, FastTree& out) {
+namespace {
+// cone of unit normals: axis c, half-angle alpha; `valid` false = "no useful cone" (wider than ~89 degrees)
+struct DCone {
+    double c[3] = {0, 0, 0}, alpha = 4.0;
+    bool valid = false;
+};
+DCone merge(const DCone& a, const DCone& b_) {
+    DCone out;
+    if (!a.valid || !b_.valid) return out;
+    DCone b = b_;
+    if (a.c[0] * b.c[0] + a.c[1] * b.c[1] + a.c[2] * b.c[2] < 0.0)
+        for (double& x : b.c) x = -x;
+    double s[3] = {a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]};
+    const double len = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    if (!(len > 1e-9)) return out;
+    for (double& x : s) x /= len;
+    auto ang = [&](const double v[3]) { return std::acos(std::min(1.0, std::max(-1.0, s[0] * v[0] + s[1] * v[1] + s[2] * v[2]))); };
+    out.alpha = std::max(ang(a.c) + a.alpha, ang(b.c) + b.alpha) + 1e-9;
+    if (!(out.alpha < 1.55)) return DCone{};
+    for (int i = 0; i < 3; ++i) out.c[i] = s[i];
+    out.valid = true;
+    return out;
+}
+}  // namespace
+
+bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out) {
     out = FastTree{};
     if (node_count == 0 || index_len == 0) return false;
     // ---- reference visit order (right child first, shader.wgsl:376-387) and per-slot metadata
     out.ref_parent.assign(node_count, 0u);
     out.slot_meta.assign(static_cast<size_t>(index_len) * 2, 0xFFFFFFFFu);
     std::vector<uint32_t> st{0u};
-    std::vector<uint32_t> slots;
+    std::vector<uint32_t> slots, order;   // order: reachable nodes, parents before children
     uint32_t rank = 0;
     while (!st.empty()) {
         const uint32_t ni = st.back();
         st.pop_back();
+        order.push_back(ni);
         const rb_bvh_node& n = ref_nodes[ni];
         if (n.primitive_count > 0) {
             for (uint32_t i = 0; i < n.primitive_count; ++i) {
                 const uint32_t slot = n.first_primitive + i;
                 if (slot >= index_len) continue;                     // guard :331
                 if (indices[slot] >= tri_count) { ++rank; continue; }  // guard :336
-                if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the exact walk
+                if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the reference walk
                 out.slot_meta[slot * 2] = ni;
                 out.slot_meta[slot * 2 + 1] = rank++;
                 slots.push_back(slot);
@@ -521,22 +473,90 @@ bool fast_bvh_prepare(uint32_t tri_count, const uint32_t* indices, uint32_t inde
         }
     }
     if (slots.empty() || slots.size() >= (1u << 28)) return false;
+    // ---- per reference node: the cone of the triangle normals below it (bottom-up: leaves from their triangles,
+    // inner nodes by merging their children's cones), for the walk's second pass over near-degenerate hits
+    std::vector<DCone> cones(node_count);
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t ni = order[k];
+        const rb_bvh_node& n = ref_nodes[ni];
+        DCone c;
+        if (n.primitive_count > 0) {
+            // direct: axis = normalised sum of the sign-aligned normals, alpha = largest angle to it
+            std::vector<std::array<double, 3>> nrm;
+            bool ok = true;
+            for (uint32_t i = 0; i < n.primitive_count && ok; ++i) {
+                const uint32_t slot = n.first_primitive + i;
+                if (slot >= index_len || indices[slot] >= tri_count) continue;
+                const rb_gpu_triangle& t = tris[indices[slot]];
+                double e1[3], e2[3];
+                for (int a = 0; a < 3; ++a) {
+                    e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
+                    e2[a] = double(t.v2[a] - t.v0[a]);
+                }
+                const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+                if (!(nn > 0.0) || !std::isfinite(nn)) { ok = false; break; }   // no normal: any direction "grazes" it
+                nrm.push_back({nx / nn, ny / nn, nz / nn});
+            }
+            if (ok && nrm.empty()) {   // nothing testable below: never needs a visit (alpha = 0 around any axis)
+                c.valid = true; c.alpha = -1.0; c.c[0] = 1.0;   // alpha < 0 marks "empty" for the merges above it
+            } else if (ok) {
+                double sum[3] = {0, 0, 0};
+                for (const auto& v : nrm) {
+                    const double sg = (v[0] * nrm[0][0] + v[1] * nrm[0][1] + v[2] * nrm[0][2]) < 0.0 ? -1.0 : 1.0;
+                    for (int a = 0; a < 3; ++a) sum[a] += sg * v[a];
+                }
+                const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+                if (len > 1e-9) {
+                    double cmin = 1.0;
+                    for (int a = 0; a < 3; ++a) c.c[a] = sum[a] / len;
+                    for (const auto& v : nrm) cmin = std::min(cmin, std::fabs(v[0] * c.c[0] + v[1] * c.c[1] + v[2] * c.c[2]));
+                    c.alpha = std::acos(std::min(1.0, cmin)) + 1e-9;
+                    c.valid = c.alpha < 1.55;
+                }
+            }
+        } else {
+            const bool hl = n.left < node_count, hr = n.right < node_count;
+            if (hl && hr) {
+                const DCone &a = cones[n.left], &b = cones[n.right];
+                if (a.valid && a.alpha < 0.0) c = b;          // an empty side adds nothing
+                else if (b.valid && b.alpha < 0.0) c = a;
+                else c = merge(a, b);
+            } else if (hl) c = cones[n.left];
+            else if (hr) c = cones[n.right];
+            else { c.valid = true; c.alpha = -1.0; c.c[0] = 1.0; }
+        }
+        cones[ni] = c;
+    }
+    out.ref_cones.assign(static_cast<size_t>(node_count) * 4, 0.0f);   // all zeros = "always possible"
+    for (uint32_t ni = 0; ni < node_count; ++ni) {
+        const DCone& c = cones[ni];
+        float* o = &out.ref_cones[static_cast<size_t>(ni) * 4];
+        if (!c.valid) continue;
+        if (c.alpha < 0.0) continue;   // nothing testable below: left as "always possible" (a wasted visit at worst)
+        const double cos_a = std::cos(c.alpha) * (1.0 - 1e-6) - 1e-7;
+        if (!(cos_a > 0.0175)) continue;
+        const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
+        o[0] = static_cast<float>(c.c[0] * cos_a);
+        o[1] = static_cast<float>(c.c[1] * cos_a);
+        o[2] = static_cast<float>(c.c[2] * cos_a);
+        o[3] = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
+    }
     out.slots = std::move(slots);
     return true;
 }
 
 bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                     const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
-    if (!fast_bvh_prepare(tri_count, indices, index_len, ref_nodes, node_count, out)) return false;
+    if (!fast_bvh_prepare(tris, tri_count, indices, index_len, ref_nodes, node_count, out)) return false;
     const std::vector<uint32_t> slots = std::move(out.slots);
-    // ---- tight boxes, normals and L^2 / N per item; items are indices into `slots`
+    // ---- tight boxes per item; items are indices into `slots`
     const size_t n = slots.size();
-    std::vector<float> bmn(n * 3), bmx(n * 3), rmn(n * 3), rmx(n * 3);
-    std::vector<ItemGeom> geo(n);
+    std::vector<float> bmn(n * 3), bmx(n * 3), q(n);
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
         const rb_gpu_triangle& t = tris[indices[slots[i]]];
-        double e1[3], e2[3], l1 = 0, l2 = 0;
+        double l1 = 0, l2 = 0, e1[3], e2[3];
         for (int a = 0; a < 3; ++a) {
             e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
             e2[a] = double(t.v2[a] - t.v0[a]);
@@ -545,16 +565,8 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
         }
         const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
         const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
-        ItemGeom g{{0, 0, 0}, std::numeric_limits<double>::infinity()};
-        if (nn > 0.0 && std::isfinite(nn)) {
-            g.n[0] = nx / nn; g.n[1] = ny / nn; g.n[2] = nz / nn;
-            g.q = std::max(l1, l2) / nn * (1.0 + 1e-9);
-        }
-        geo[i] = g;
-        const rb_bvh_node& leaf = ref_nodes[out.slot_meta[static_cast<size_t>(slots[i]) * 2]];
+        q[i] = (nn > 0.0 && std::isfinite(nn)) ? static_cast<float>(std::max(l1, l2) / nn * 1.000001) : kInf;
         for (int a = 0; a < 3; ++a) {
-            rmn[i * 3 + a] = leaf.aabb_min[a];
-            rmx[i * 3 + a] = leaf.aabb_max[a];
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
             smn[a] = std::min(smn[a], bmn[i * 3 + a]);
@@ -566,7 +578,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     // up to 64 threads at the sixth level; RB_HOST_BUILD_SEQUENTIAL=1 (debug) builds on one thread -- the
     // tree is the same either way (tests/test_gpu_parity.py compares the walk's counters)
     const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
-    FBuilder fb{bmn, bmx, rmn, rmx, geo, items, out.nodes, out.cones, out.rboxes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
+    FBuilder fb{bmn, bmx, q, items, out.nodes, stack_limit, 0, (seq && seq[0] == '1') ? 0u : 6u};
     out.root = fb.build(0, n, 1);
     out.depth = fb.max_depth + 1;
     out.slots.resize(n);

@@ -234,38 +234,31 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 //  * the reference only tests a triangle if every node from the root to its leaf passes intersect_aabb: an
 //    improving candidate is accepted only after that chain has been re-checked with the reference's own slab
 //    arithmetic on the reference's boxes;
-//  * a subtree is skipped only when NO triangle below it can be an accepted hit of the reference for this ray
-//    (entry()): neither one the reference's f32 Moller-Trumbore reports near its triangle (A), nor one it
-//    reports from a near-zero determinant, possibly far away (B).  So the reference's winner is always among
-//    the candidates.
+//  * no triangle the reference would report as hit is ever lost to culling.  The reference's f32
+//    Moller-Trumbore can report a hit some distance from its triangle; that distance is bounded as long as the
+//    ray is not nearly parallel to the triangle's plane.  Hits are therefore split by c0 = kFastGrazeCos:
+//      (A) |cos(ray, normal)| >= c0: a subtree of the library's tree is skipped only if the ray misses its box
+//          inflated by a margin that covers every such hit below it (entry());
+//      (B) |cos| < c0 (the ray is within ~1.7 degrees of the triangle's plane; no useful bound exists): found by a
+//          second pass over the REFERENCE tree with the reference's own slab tests, entering only nodes whose
+//          normal cone admits such a triangle, and testing only the triangles of a leaf that are (graze_pass()).
+//    Both passes offer their candidates to the same closest-hit rule, so the reference's winner is always among them.
 // The walk is a resumable object so that the same steps serve the per-segment kernels (intersect_bvh_fast
 // below: run to completion) and the stepped kernel (k_trace_fast: lanes that finish are shaded and refilled
 // while the others keep walking).
 //
-// When may a child box be skipped for the ray (o, d), |d| = 1 +- 4 ulp?  For a triangle k below it with
-// L = max(|e1|, |e2|), N = |e1 x e2|, s = o - v0, a = d . (e2 x e1) = N cos(d, n_k), and the reference's computed
-// determinant a^ (a hit is accepted only if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies
-// (u = 2^-24, first order, every rounding of shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract;
-// DESIGN.md section 4, E1-E7)
+// (A) in numbers.  For the ray (o, d), |d| = 1 +- 4 ulp, and a triangle k with L = max(|e1|, |e2|), N = |e1 x e2|,
+// s = o - v0, a = d . (e2 x e1) = N cos(d, n_k) and the reference's computed determinant a^ (a hit is accepted only
+// if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies (u = 2^-24, first order, every rounding of
+// shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract)
 //     dist_inf(X, box(triangle k)) <= 26 u (|s| + L) L^2 / |a_k|  +  7.5 u (|s| + 2 L)
-// as long as 5.42 u L^2 / |a^| <= 0.05.  Split the triangles below the child by c0 = kFastGrazeCos:
-//  (A) |cos(d, n_k)| >= c0.  Then L^2 / |a_k| <= (max_k L_k^2 / N_k) / c0, a per-child constant FA (stored with
-//      the 0.95 that bounds |a^| >= 0.95 |a|, +inf beyond 1.5e5 where no bound is claimed), and with
-//      |s| + 2 L <= Sp = (distance from o to the child box's farthest corner) + 2 (sum of its extents), plus 10 u Sp
-//      for the rounding of the slab test itself, X lies inside the child's box inflated by
-//          margin = Sp (27 u FA + 20 u),
-//      entered no later than t^: the usual slab test with that margin and the cull `entry > best t` are safe.
-//  (B) |cos(d, n_k)| < c0: the ray is within ~1.7 degrees of the triangle's plane and no useful bound on X
-//      exists.  But the reference tests a triangle only if the ray passes its REFERENCE leaf's box
-//      (shader.wgsl:318-327), whatever Moller-Trumbore then reports.  Every child also stores R, the union of
-//      the reference leaf boxes of its triangles: if the ray misses R (inflated by the slab test's own
-//      rounding), the reference tests none of them.  (B) can only apply if some normal below is within
-//      asin(c0) of perpendicular to d: every unit normal below lies within angle alpha of +-c (the child's
-//      cone), so |cos(d, n_k)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with x = |d . c|; if that lower
-//      bound is >= c0 there is no class-(B) triangle and R is not even fetched.
-// A child is entered iff (A) passes, or (B) is possible and the ray hits R.  The (B) path has no t-cull (a
-// near-degenerate hit's t^ is not tied to where the triangle is).  Per child: FA (the node's two pad words),
-// {c cos(alpha), tan(alpha)} (FastCone), R (FastRBox), all rounded outwards by the builders.
+// as long as 5.42 u L^2 / |a^| <= 0.05.  With |cos| >= c0: L^2 / |a_k| <= (max_k L_k^2 / N_k) / c0, a per-child
+// constant FA (stored in the node's pad words with the 0.95 that bounds |a^| >= 0.95 |a|; +inf = always enter,
+// beyond 1.5e5 where no bound is claimed or for a triangle with N = 0); |s| + 2 L <= Sp = (distance from o to the
+// child box's farthest corner) + 2 (sum of its extents); plus 10 u Sp for the rounding of the slab test itself:
+//     margin = Sp (27 u FA + 20 u),
+// and X is inside the box so inflated, entered no later than t^: the slab test with that margin and the cull
+// `entry > best t` are safe.
 constexpr float kFastKF = 27.0f * 5.9604645e-8f * 1.01f;
 constexpr float kFastKS = 20.0f * 5.9604645e-8f * 1.01f;
 template <bool STATS>
@@ -326,9 +319,7 @@ struct FastWalk {
     // visit the child unless the ray misses its inflated box or enters it beyond the best t (comparisons are
     // written so that a NaN means "visit").  This arithmetic only steers the walk: fused operations and the
     // hardware's approximate sqrt / rcp are fine as long as every rounding is on the safe side.
-    // `rbox`: the two float4 of this child's R in p.fast_rboxes.
-    DEV bool entry(v4f lo, v4f hi, v4f cone, float fa, cf4p rbox, float& tn) const {
-        // ---- (A)
+    DEV bool entry(v4f lo, v4f hi, float fa, float& tn) const {
         const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
         const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
         // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
@@ -339,35 +330,84 @@ struct FastWalk {
         const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
         tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
         const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
-        if (!(tf < fmaxf(tn, 0.0f)) && !(tn > h.t)) return true;
-        // ---- (B) possible?  lower bound of |cos(d, n)| over the cone: cone.xyz = c cos(alpha), cone.w = tan(alpha);
-        // y = |d . c| cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2 (an invalid cone is all zeros: bound 0)
+        return !(tf < fmaxf(tn, 0.0f)) && !(tn > h.t);
+    }
+
+    // (B): can a triangle with |cos(d, n)| < c0 lie below a reference node?  cone = {c cos(alpha), tan(alpha)},
+    // every unit normal below is within alpha of +-c, so |cos(d, n)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with
+    // x = |d . c|.  y = x cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible.
+    DEV bool graze_possible(v4f cone) const {
         const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
         const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
         const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);
         const float lb = __builtin_fmaf(-cone.w, root, y - 1e-6f);
-        if (lb >= kFastGrazeCos) return false;   // every triangle below is class (A), and (A) failed
-        const v4f r0 = rbox[0], r1 = rbox[1];
-        const f3 ra = mk(r0.x - m_ref, r0.y - m_ref, r0.z - m_ref) - o, rb = mk(r1.x + m_ref, r1.y + m_ref, r1.z + m_ref) - o;
-        const f3 u0 = ra * inv, u1 = rb * inv;
-        const float rn = fmaxf(fmaxf(fminf(u0.x, u1.x), fminf(u0.y, u1.y)), fminf(u0.z, u1.z));
-        const float rf = fminf(fminf(fmaxf(u0.x, u1.x), fmaxf(u0.y, u1.y)), fmaxf(u0.z, u1.z));
-        tn = rn;
-        return !(rf < fmaxf(rn, 0.0f));
+        return !(lb >= kFastGrazeCos);
+    }
+    // The second pass: the reference's own walk (shader.wgsl:309-389: same nodes, same slab arithmetic, so a leaf
+    // is reached exactly when the reference tests its triangles), restricted to nodes that can hold a class-(B)
+    // triangle, and in a leaf to the triangles that are class (B) for this ray (the prepared unit normal is the
+    // reference's f32 normalize(cross(e1, e2)), within 3e-7 of the true one).  Candidates go through the
+    // reference's intersect_triangle and the closest-hit rule of leaf_step; the visit order does not matter
+    // because equal t resolves by reference rank.  Uses the walk's (now empty) stack.
+    DEV void graze_pass(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        const cf4p rnodes = (cf4p)p.nodes;
+        const cf4p rcones = (cf4p)p.ref_cones;
+        const cf4p ptris = (cf4p)p.ptris;
+        const RB_CONST uint32_t* meta = cptr(p.slot_meta);
+        const uint32_t node_count = p.u.bvh_node_count;
+        int gp = 1;
+        stack[0] = 0u;
+        while (gp > 0) {
+            gp--;
+            const uint32_t ni = stack[gp * stride];
+            if (ni >= node_count) continue;
+            if (!graze_possible(rcones[ni])) continue;
+            const v4f n0 = rnodes[ni * 3u], n1 = rnodes[ni * 3u + 1u];
+            if constexpr (STATS) tl.nodes++;
+            if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
+            const v4u n2 = ((cu4p)p.nodes)[ni * 3u + 2u];
+            if (n2.w == 0u) {
+                if (n2.x < node_count) { stack[gp * stride] = n2.x; gp++; }
+                if (n2.y < node_count) { stack[gp * stride] = n2.y; gp++; }
+                continue;
+            }
+            const uint32_t end = (n2.z + n2.w < p.index_len) ? n2.z + n2.w : p.index_len;
+            for (uint32_t slot = n2.z; slot < end; slot++) {
+                const v4f nr = ptris[slot * 4u + 3u];
+                // prepared normal vs true normal: the f32 cross product is off by <= 2.42 u L^2, i.e. the direction by
+                // <= 2.5 u q + 3 u <= 6.5e-4 rad for every triangle (A) has a finite margin for (q <= 4275); a
+                // triangle beyond that (or without a normal: NaN here) has FA = +inf and is never culled by (A)
+                if (!(fabsf(__builtin_fmaf(d.z, nr.z, __builtin_fmaf(d.y, nr.y, d.x * nr.x))) < kFastGrazeCos * 1.03f)) continue;
+                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+                if constexpr (STATS) tl.tris++;
+                float u, v;
+                const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+                if (t > 0.001f && !(t > h.t)) {
+                    const uint32_t rank = meta[slot * 2u + 1u];
+                    if (t < h.t || rank < best_rank) {
+                        h.hit = true;
+                        h.t = t;
+                        h.u = u;
+                        h.v = v;
+                        h.slot = slot;
+                        best_rank = rank;
+                        if constexpr (STATS) tl.mesh_hits++;
+                    }
+                }
+            }
+        }
     }
 
     // cur is an internal node: descend into the nearer child that is hit, remember the other.
     // Returns false when the walk is complete.
     DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
         const cf4p nodes = (cf4p)p.fast_nodes;
-        const cf4p cones = (cf4p)p.fast_cones;
-        const cf4p rboxes = (cf4p)p.fast_rboxes + cur * 4u;
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
-        const v4f cl = cones[cur * 2u], cr = cones[cur * 2u + 1u];
         if constexpr (STATS) tl.nodes++;
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
-        const bool hl = entry(l0, l1, cl, r0.w, rboxes, tl_), hr = entry(r0, r1, cr, r1.w, rboxes + 2, tr_);
+        const bool hl = entry(l0, l1, r0.w, tl_), hr = entry(r0, r1, r1.w, tr_);
         if (hl && hr) {
             const bool left_first = !(tr_ < tl_);
             push(p, stack, stride, sp, left_first ? rref : lref);
@@ -453,6 +493,7 @@ DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uin
     w.begin(p, o, d);
     bool more = true;
     while (more) more = w.at_leaf() ? w.leaf_step(p, stack, stride, tl) : w.node_step(p, stack, stride, tl);
+    w.graze_pass(p, stack, stride, tl);
     return w.h;
 }
 

@@ -45,26 +45,15 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 constexpr bool kFastWalkByDefault = RB_FAST_WALK_DEFAULT != 0;
 constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the library's tree is built on the device by default
 
-// Per node of the library's triangle tree, next to its 64-B SphereNode (whose two pad words hold FA of each
-// child): for each child a cone that contains the (unoriented) normals of the triangles below it, as
-// {axis * cos(alpha), tan(alpha)}, and R, the union of the reference leaf boxes of those triangles
-// (rb_device_intersect.hpp, FastWalk::entry).
-constexpr float kFastGrazeCos = 0.03f;   // c0: |cos(ray, triangle normal)| below which a hit counts as "near-degenerate"
-struct alignas(16) FastCone {
-    float l[4];
-    float r[4];
-};
-static_assert(sizeof(FastCone) == 32, "FastCone is 32 B");
-struct alignas(16) FastRBox {
-    float lmin[4], lmax[4], rmin[4], rmax[4];
-};
-static_assert(sizeof(FastRBox) == 64, "FastRBox is 64 B");
+// c0 of the library's triangle walk (rb_device_intersect.hpp, FastWalk): hits with
+// |cos(ray, triangle normal)| >= c0 are covered by the culling margin of the library's tree (FA in each node's two
+// pad words), the others by a second pass over the reference tree guided by per-node normal cones.
+constexpr float kFastGrazeCos = 0.03f;
 
 // The library's own triangle tree (rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
 struct FastTree {
     std::vector<SphereNode> nodes;
-    std::vector<FastCone> cones;       // one per node
-    std::vector<FastRBox> rboxes;      // one per node
+    std::vector<float> ref_cones;      // per REFERENCE node: {axis cos(alpha) (3), tan(alpha)} of the normals below it
     std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
     std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
@@ -77,8 +66,8 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
                     const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out);
 // The part of it that depends on the reference tree only: ref_parent, slot_meta, and `slots` = the
 // valid slots in the reference's visit order (the items a builder then arranges into a tree).
-bool fast_bvh_prepare(uint32_t tri_count, const uint32_t* indices, uint32_t index_len, const rb_bvh_node* ref_nodes,
-                      uint32_t node_count, FastTree& out);
+bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out);
 
 // ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
 struct DeviceTreeInfo {
@@ -87,8 +76,7 @@ struct DeviceTreeInfo {
     float bmin[3], bmax[3];
 };
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          const uint32_t* slot_meta, const rb_bvh_node* ref_nodes, SphereNode* nodes_out, FastCone* cones_out,
-                          FastRBox* rboxes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream,
+                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream,
                           bool plain_lbvh);
 
 // ---- device-side counters (one block of u64 in device memory)
@@ -133,8 +121,7 @@ struct KParams {
     const rb_texture_info* tex_info;
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
     const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
-    const FastCone* fast_cones;    // per node: the children's normal cones
-    const FastRBox* fast_rboxes;   // per node: the children's reference-leaf boxes
+    const float* ref_cones;        // per reference node: float4 {axis cos(alpha), tan(alpha)} of the normals below it
     const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
     const uint32_t* fast_slots;    // fast-leaf order -> slot
     const uint32_t* slot_meta;     // per slot {reference leaf node, reference rank}

@@ -532,6 +532,7 @@ struct TriangleWalkPolicy {
     DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.node_step(p, stack, kTraceBlock, tl); }
     DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.leaf_step(p, stack, kTraceBlock, tl); }
     DEV bool finish(const KParams& p, Path& pt, uint32_t* stack, Tally<STATS>& tl) {
+        w.graze_pass(p, stack, kTraceBlock, tl);   // the hits the culled walk cannot vouch for (FastWalk, class (B))
         return segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
     }
 };

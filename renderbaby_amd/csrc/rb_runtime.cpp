@@ -122,8 +122,7 @@ struct rb_engine {
     DevBuf<rb::SphereNode> fast_nodes; // the library's own triangle tree (walk mode "fast")
     DevBuf<rb::PrepTri> fast_tris;
     DevBuf<uint32_t> fast_slots, slot_meta, ref_parent, stack_overflow;
-    DevBuf<rb::FastCone> fast_cones;
-    DevBuf<rb::FastRBox> fast_rboxes;
+    DevBuf<float> ref_cones;
     uint32_t fast_root = 0, fast_depth = 0;
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
@@ -548,21 +547,17 @@ int ensure_prepared(rb_engine* e) {
         const bool try_device = !force_host && (force_dev || n_tris >= rb::kDeviceBuildMinTriangles);
         if (try_device) {
             // reference-order metadata on the host (one pass over the caller's tree), the tree on the device
-            if (rb::fast_bvh_prepare(n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft) &&
+            if (rb::fast_bvh_prepare(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft) &&
                 ft.slots.size() >= 1024) {
                 const uint32_t n = static_cast<uint32_t>(ft.slots.size());
                 DevBuf<uint32_t> visit_slots;
                 rc = upload(e, visit_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
-                if (!rc) rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
                 if (rc) return rc;
                 HIP_TRY(e, e->fast_nodes.resize(n - 1));
-                HIP_TRY(e, e->fast_cones.resize(n - 1));
-                HIP_TRY(e, e->fast_rboxes.resize(n - 1));
                 HIP_TRY(e, e->fast_slots.resize(n));
                 rb::DeviceTreeInfo info{};
-                rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->slot_meta.ptr, e->nodes.ptr,
-                                               e->fast_nodes.ptr, e->fast_cones.ptr, e->fast_rboxes.ptr, e->fast_slots.ptr,
-                                               &info, e->stream, (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
+                rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
+                                               e->fast_slots.ptr, &info, e->stream, (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
                 if (rc && rc != static_cast<int>(hipErrorNotReady))
                     return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
                 if (rc) info.depth = 0xFFFFFFFFu;  // clustering did not converge within its round limit: host builder
@@ -594,14 +589,13 @@ int ensure_prepared(rb_engine* e) {
                                     rb::kStackDepth, ft))
                 return RB_OK;  // keep the reference walk
             rc = upload(e, e->fast_nodes, ft.nodes.data(), ft.nodes.size(), nullptr, true);
-            if (!rc) rc = upload(e, e->fast_cones, ft.cones.data(), ft.cones.size(), nullptr, true);
-            if (!rc) rc = upload(e, e->fast_rboxes, ft.rboxes.data(), ft.rboxes.size(), nullptr, true);
             if (!rc) rc = upload(e, e->fast_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
             if (rc) return rc;
             e->fast_builder = "host-sah";
         }
         rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
         if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
+        if (!rc) rc = upload(e, e->ref_cones, ft.ref_cones.data(), ft.ref_cones.size(), nullptr, true);
         if (rc) return rc;
         const size_t n_items = e->fast_slots.count;
         HIP_TRY(e, e->fast_tris.resize(n_items));
@@ -660,8 +654,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     p.colors = e->colors.ptr;
     const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
-    p.fast_cones = e->fast_cones.ptr;
-    p.fast_rboxes = e->fast_rboxes.ptr;
+    p.ref_cones = e->ref_cones.ptr;
     p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
     p.fast_slots = e->fast_slots.ptr;
     p.slot_meta = e->slot_meta.ptr;

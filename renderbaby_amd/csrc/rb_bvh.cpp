@@ -528,10 +528,19 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         }
         cones[ni] = c;
     }
-    out.ref_cones.assign(static_cast<size_t>(node_count) * 4, 0.0f);   // all zeros = "always possible"
+    // one 64-B record per reference node for that pass: the reference's box and links, bit for bit, plus the cone
+    out.gnodes.assign(node_count, GrazeNode{});
     for (uint32_t ni = 0; ni < node_count; ++ni) {
+        const rb_bvh_node& n = ref_nodes[ni];
+        GrazeNode& g = out.gnodes[ni];
+        std::memcpy(g.bmin, n.aabb_min, 12);
+        std::memcpy(g.bmax, n.aabb_max, 12);
+        g.left = n.left;
+        g.right = n.right;
+        g.first = n.first_primitive;
+        g.count = n.primitive_count;
         const DCone& c = cones[ni];
-        float* o = &out.ref_cones[static_cast<size_t>(ni) * 4];
+        float* o = g.cone;   // all zeros = "always possible"
         if (!c.valid) continue;
         if (c.alpha < 0.0) continue;   // nothing testable below: left as "always possible" (a wasted visit at worst)
         const double cos_a = std::cos(c.alpha) * (1.0 - 1e-6) - 1e-7;

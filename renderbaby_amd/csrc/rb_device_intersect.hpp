@@ -241,7 +241,7 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 //          inflated by a margin that covers every such hit below it (entry());
 //      (B) |cos| < c0 (the ray is within ~1.7 degrees of the triangle's plane; no useful bound exists): found by a
 //          second pass over the REFERENCE tree with the reference's own slab tests, entering only nodes whose
-//          normal cone admits such a triangle, and testing only the triangles of a leaf that are (graze_pass()).
+//          normal cone admits such a triangle, and testing only the triangles of a leaf that are (gnode_step / gleaf_step).
 //    Both passes offer their candidates to the same closest-hit rule, so the reference's winner is always among them.
 // The walk is a resumable object so that the same steps serve the per-segment kernels (intersect_bvh_fast
 // below: run to completion) and the stepped kernel (k_trace_fast: lanes that finish are shaded and refilled
@@ -267,7 +267,9 @@ struct FastWalk {
     float m_ref;        // shrink of a reference leaf box for the chain shortcut (reference_would_test)
     TriHit h;
     uint32_t best_rank;
-    uint32_t cur;       // current child reference (leaf: bit 31)
+    uint32_t cur;       // current child reference (leaf: bit 31); second pass: reference node, or bit 31 | next slot of a leaf
+    uint32_t gend;      // second pass: end of the leaf being scanned
+    bool graze;         // false: the culled walk of the library's tree (A); true: the second pass over the reference tree (B)
     int sp;
 
     DEV void begin(const KParams& p, f3 o_, f3 d_) {
@@ -287,9 +289,13 @@ struct FastWalk {
                     sz_ = fmaxf(fabsf(o.z - fb0.z), fabsf(o.z - fb1.z));
         m_ref = 1e-6f * sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_) + 1e-30f;
         cur = p.fast_root;
+        gend = 0u;
+        graze = false;
         sp = 0;
     }
     DEV bool at_leaf() const { return (cur & 0x80000000u) != 0u; }
+    // which step this lane needs next: 0 node / 1 leaf of the library's tree, 2 node / 3 leaf chunk of the second pass
+    DEV uint32_t kind() const { return (graze ? 2u : 0u) | (cur >> 31); }
 
     // Entries beyond the LDS stack (trees deeper than kStackDepth: only device-built ones, the host
     // builder limits its depth) spill to this lane's column of a global scratch array.
@@ -308,9 +314,15 @@ struct FastWalk {
         else v = *spill(p, at);
         return v;
     }
-    // next pending subtree; false when the walk is complete
+    // next pending subtree; when the library's tree is done the second pass starts at the reference root;
+    // false when both are complete
     DEV bool pop(const KParams& p, const uint32_t* stack, uint32_t stride) {
-        if (sp == 0) return false;
+        if (sp == 0) {
+            if (graze) return false;
+            graze = true;
+            cur = 0u;
+            return true;
+        }
         sp--;
         cur = peek(p, stack, stride, sp);
         return true;
@@ -346,56 +358,87 @@ struct FastWalk {
     // The second pass: the reference's own walk (shader.wgsl:309-389: same nodes, same slab arithmetic, so a leaf
     // is reached exactly when the reference tests its triangles), restricted to nodes that can hold a class-(B)
     // triangle, and in a leaf to the triangles that are class (B) for this ray (the prepared unit normal is the
-    // reference's f32 normalize(cross(e1, e2)), within 3e-7 of the true one).  Candidates go through the
-    // reference's intersect_triangle and the closest-hit rule of leaf_step; the visit order does not matter
-    // because equal t resolves by reference rank.  Uses the walk's (now empty) stack.
-    DEV void graze_pass(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
-        const cf4p rnodes = (cf4p)p.nodes;
-        const cf4p rcones = (cf4p)p.ref_cones;
-        const cf4p ptris = (cf4p)p.ptris;
-        const RB_CONST uint32_t* meta = cptr(p.slot_meta);
-        const uint32_t node_count = p.u.bvh_node_count;
-        int gp = 1;
-        stack[0] = 0u;
-        while (gp > 0) {
-            gp--;
-            const uint32_t ni = stack[gp * stride];
-            if (ni >= node_count) continue;
-            if (!graze_possible(rcones[ni])) continue;
-            const v4f n0 = rnodes[ni * 3u], n1 = rnodes[ni * 3u + 1u];
+    // reference's f32 normalize(cross(e1, e2))).  Candidates go through the reference's intersect_triangle and the
+    // closest-hit rule of leaf_step; the visit order does not matter because equal t resolves by reference rank.
+    // Resumable like the first pass: one reference node per gnode_step, up to kGrazeChunk triangles per gleaf_step,
+    // on the same (by now empty) stack.
+    static constexpr uint32_t kGrazeChunk = 16u;
+    DEV bool gnode_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        const cf4p gn = (cf4p)p.gnodes + (size_t)cur * 4u;
+        const v4f cone = gn[2];
+        if (graze_possible(cone)) {
+            const v4f n0 = gn[0], n1 = gn[1];
             if constexpr (STATS) tl.nodes++;
-            if (!isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) continue;
-            const v4u n2 = ((cu4p)p.nodes)[ni * 3u + 2u];
-            if (n2.w == 0u) {
-                if (n2.x < node_count) { stack[gp * stride] = n2.x; gp++; }
-                if (n2.y < node_count) { stack[gp * stride] = n2.y; gp++; }
-                continue;
-            }
-            const uint32_t end = (n2.z + n2.w < p.index_len) ? n2.z + n2.w : p.index_len;
-            for (uint32_t slot = n2.z; slot < end; slot++) {
-                const v4f nr = ptris[slot * 4u + 3u];
-                // prepared normal vs true normal: the f32 cross product is off by <= 2.42 u L^2, i.e. the direction by
-                // <= 2.5 u q + 3 u <= 6.5e-4 rad for every triangle (A) has a finite margin for (q <= 4275); a
-                // triangle beyond that (or without a normal: NaN here) has FA = +inf and is never culled by (A)
-                if (!(fabsf(__builtin_fmaf(d.z, nr.z, __builtin_fmaf(d.y, nr.y, d.x * nr.x))) < kFastGrazeCos * 1.03f)) continue;
-                const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
-                if (__float_as_uint(c.w) == 0u) continue;  // guard :336
-                if constexpr (STATS) tl.tris++;
-                float u, v;
-                const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
-                if (t > 0.001f && !(t > h.t)) {
-                    const uint32_t rank = meta[slot * 2u + 1u];
-                    if (t < h.t || rank < best_rank) {
-                        h.hit = true;
-                        h.t = t;
-                        h.u = u;
-                        h.v = v;
-                        h.slot = slot;
-                        best_rank = rank;
-                        if constexpr (STATS) tl.mesh_hits++;
+            if (isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
+                const v4u n3 = ((cu4p)gn)[3];
+                const uint32_t node_count = p.u.bvh_node_count;
+                if (n3.y > 0u) {   // leaf: scan [first, first + count) below index_len (guard :331)
+                    const uint32_t end = (n3.x + n3.y < p.index_len) ? n3.x + n3.y : p.index_len;
+                    if (n3.x < end) {
+                        cur = 0x80000000u | n3.x;
+                        gend = end;
+                        return true;
+                    }
+                } else {
+                    const uint32_t l = __float_as_uint(n0.w), r = __float_as_uint(n1.w);
+                    const bool hl = l < node_count, hr = r < node_count;   // guards :376-387
+                    if (hl && hr) {
+                        stack[sp * stride] = r;
+                        sp++;
+                        cur = l;
+                        return true;
+                    }
+                    if (hl || hr) {
+                        cur = hl ? l : r;
+                        return true;
                     }
                 }
             }
+        }
+        return pop(p, stack, stride);
+    }
+    DEV bool gleaf_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        const cf4p ptris = (cf4p)p.ptris;
+        const RB_CONST uint32_t* meta = cptr(p.slot_meta);
+        uint32_t slot = cur & 0x7FFFFFFFu;
+        const uint32_t stop = (slot + kGrazeChunk < gend) ? slot + kGrazeChunk : gend;
+        for (; slot < stop; slot++) {
+            const v4f nr = ptris[slot * 4u + 3u];
+            // prepared normal vs true normal: the f32 cross product is off by <= 2.42 u L^2, i.e. the direction by
+            // <= 2.5 u q + 3 u <= 6.5e-4 rad for every triangle (A) has a finite margin for (q <= 4275); a
+            // triangle beyond that (or without a normal: NaN here) has FA = +inf and is never culled by (A)
+            if (!(fabsf(__builtin_fmaf(d.z, nr.z, __builtin_fmaf(d.y, nr.y, d.x * nr.x))) < kFastGrazeCos * 1.03f)) continue;
+            const v4f a = ptris[slot * 4u], b = ptris[slot * 4u + 1u], c = ptris[slot * 4u + 2u];
+            if (__float_as_uint(c.w) == 0u) continue;  // guard :336
+            if constexpr (STATS) tl.tris++;
+            float u, v;
+            const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
+            if (t > 0.001f && !(t > h.t)) {
+                const uint32_t rank = meta[slot * 2u + 1u];
+                if (t < h.t || rank < best_rank) {
+                    h.hit = true;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.slot = slot;
+                    best_rank = rank;
+                    if constexpr (STATS) tl.mesh_hits++;
+                }
+            }
+        }
+        if (slot < gend) {
+            cur = 0x80000000u | slot;
+            return true;
+        }
+        return pop(p, stack, stride);
+    }
+    // one step of whatever kind this lane needs; false when the walk is complete
+    DEV bool step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
+        switch (kind()) {
+            case 0u: return node_step(p, stack, stride, tl);
+            case 1u: return leaf_step(p, stack, stride, tl);
+            case 2u: return gnode_step(p, stack, stride, tl);
+            default: return gleaf_step(p, stack, stride, tl);
         }
     }
 
@@ -491,9 +534,8 @@ template <bool STATS>
 DEV TriHit intersect_bvh_fast(const KParams& p, f3 o, f3 d, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     FastWalk<STATS> w;
     w.begin(p, o, d);
-    bool more = true;
-    while (more) more = w.at_leaf() ? w.leaf_step(p, stack, stride, tl) : w.node_step(p, stack, stride, tl);
-    w.graze_pass(p, stack, stride, tl);
+    while (w.step(p, stack, stride, tl)) {
+    }
     return w.h;
 }
 

@@ -49,11 +49,22 @@ constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the librar
 // |cos(ray, triangle normal)| >= c0 are covered by the culling margin of the library's tree (FA in each node's two
 // pad words), the others by a second pass over the reference tree guided by per-node normal cones.
 constexpr float kFastGrazeCos = 0.03f;
+// A node of the reference tree as that second pass reads it: the caller's box and links bit for bit (the pass
+// repeats the reference's own slab test), plus the cone {axis cos(alpha), tan(alpha)} of the triangle normals below.
+struct alignas(16) GrazeNode {
+    float bmin[3];
+    uint32_t left;
+    float bmax[3];
+    uint32_t right;
+    float cone[4];
+    uint32_t first, count, _pad[2];
+};
+static_assert(sizeof(GrazeNode) == 64, "GrazeNode is 64 B");
 
 // The library's own triangle tree (rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
 struct FastTree {
     std::vector<SphereNode> nodes;
-    std::vector<float> ref_cones;      // per REFERENCE node: {axis cos(alpha) (3), tan(alpha)} of the normals below it
+    std::vector<GrazeNode> gnodes;     // per REFERENCE node: its box, links and the cone of the normals below it
     std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
     std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
@@ -121,7 +132,7 @@ struct KParams {
     const rb_texture_info* tex_info;
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
     const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
-    const float* ref_cones;        // per reference node: float4 {axis cos(alpha), tan(alpha)} of the normals below it
+    const GrazeNode* gnodes;       // per reference node: box, links, normal cone (the walk's second pass)
     const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
     const uint32_t* fast_slots;    // fast-leaf order -> slot
     const uint32_t* slot_meta;     // per slot {reference leaf node, reference rank}

@@ -525,14 +525,16 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 template <bool STATS>
 struct TriangleWalkPolicy {
     static constexpr int kNodeSteps = RB_FAST_NODE_STEPS;
+    static constexpr uint32_t kKinds = 4u;   // node / leaf of the library's tree, node / leaf chunk of the second pass
     FastWalk<STATS> w;
+    DEV uint32_t kind() const { return w.kind(); }
+    DEV bool step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.step(p, stack, kTraceBlock, tl); }
     DEV void init(const KParams& p) { w.begin(p, mk(0, 0, 0), mk(0, 0, 1)); }
     DEV void begin(const KParams& p, const Path& pt, uint32_t*, Tally<STATS>&) { w.begin(p, pt.o, pt.d); }
     DEV bool at_leaf() const { return w.at_leaf(); }
     DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.node_step(p, stack, kTraceBlock, tl); }
     DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.leaf_step(p, stack, kTraceBlock, tl); }
     DEV bool finish(const KParams& p, Path& pt, uint32_t* stack, Tally<STATS>& tl) {
-        w.graze_pass(p, stack, kTraceBlock, tl);   // the hits the culled walk cannot vouch for (FastWalk, class (B))
         return segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
     }
 };
@@ -543,6 +545,11 @@ struct TriangleWalkPolicy {
 template <bool STATS>
 struct SphereWalkPolicy {
     static constexpr int kNodeSteps = RB_SPH_NODE_STEPS;
+    static constexpr uint32_t kKinds = 2u;
+    DEV uint32_t kind() const { return w.at_leaf() ? 1u : 0u; }
+    DEV bool step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) {
+        return w.at_leaf() ? leaf_step(p, stack, tl) : node_step(p, stack, tl);
+    }
     SphereWalk w;
     TriHit th;
     SegState st;
@@ -634,6 +641,27 @@ DEV void trace_stepped(const KParams& p) {
         // reaches a leaf only every ~6 nodes, so waiting for ALL lanes to reach one would leave the
         // node loop 20 % occupied).  At least one pass per outer iteration, then on while enough lanes
         // are still walking.
+        if constexpr (Walk::kKinds > 2u) {
+            // four kinds of step (FastWalk: the library's tree, then the second pass over the reference tree): every
+            // pass runs the kind most lanes are waiting for, node kinds a few steps per vote
+            for (;;) {
+                const uint32_t k = state == TRAV ? w.kind() : 4u;
+                const uint32_t n0 = (uint32_t)__popcll(__ballot(k == 0u)), n1 = (uint32_t)__popcll(__ballot(k == 1u)),
+                               n2 = (uint32_t)__popcll(__ballot(k == 2u)), n3 = (uint32_t)__popcll(__ballot(k == 3u));
+                uint32_t pick = 0u, best = n0;
+                if (n1 > best) { pick = 1u; best = n1; }
+                if (n2 > best) { pick = 2u; best = n2; }
+                if (n3 > best) { pick = 3u; best = n3; }
+                if (best == 0u) break;
+                if (k == pick) {
+                    if (!w.step(p, stack, tl)) state = FINISH;
+                    if ((pick & 1u) == 0u)   // node kinds: a lane reaches a leaf only every few nodes
+                        for (int extra = 1; extra < Walk::kNodeSteps; ++extra)
+                            if (state == TRAV && w.kind() == pick && !w.step(p, stack, tl)) state = FINISH;
+                }
+                if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
+            }
+        } else
         for (;;) {
             const bool at_node = state == TRAV && !w.at_leaf();
             const bool at_leaf = state == TRAV && w.at_leaf();

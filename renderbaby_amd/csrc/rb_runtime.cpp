@@ -122,7 +122,7 @@ struct rb_engine {
     DevBuf<rb::SphereNode> fast_nodes; // the library's own triangle tree (walk mode "fast")
     DevBuf<rb::PrepTri> fast_tris;
     DevBuf<uint32_t> fast_slots, slot_meta, ref_parent, stack_overflow;
-    DevBuf<float> ref_cones;
+    DevBuf<rb::GrazeNode> gnodes;
     uint32_t fast_root = 0, fast_depth = 0;
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
@@ -595,7 +595,7 @@ int ensure_prepared(rb_engine* e) {
         }
         rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
         if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
-        if (!rc) rc = upload(e, e->ref_cones, ft.ref_cones.data(), ft.ref_cones.size(), nullptr, true);
+        if (!rc) rc = upload(e, e->gnodes, ft.gnodes.data(), ft.gnodes.size(), nullptr, true);
         if (rc) return rc;
         const size_t n_items = e->fast_slots.count;
         HIP_TRY(e, e->fast_tris.resize(n_items));
@@ -654,7 +654,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     p.colors = e->colors.ptr;
     const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
-    p.ref_cones = e->ref_cones.ptr;
+    p.gnodes = e->gnodes.ptr;
     p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
     p.fast_slots = e->fast_slots.ptr;
     p.slot_meta = e->slot_meta.ptr;

@@ -47,7 +47,8 @@ __device__ __forceinline__ float ord2f(uint32_t k) {
 // bounds[0..2] mesh min, [3..5] mesh max, [6..8] centroid min, [9..11] centroid max (ordered uints)
 __global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __restrict__ tris,
                                                      const uint32_t* __restrict__ indices,
-                                                     const uint32_t* __restrict__ slots, uint32_t n,
+                                                     const uint32_t* __restrict__ slots,
+                                                     const uint32_t* __restrict__ slot_meta, uint32_t n,
                                                      float4* __restrict__ pmin, float4* __restrict__ pmax,
                                                      uint32_t* bounds) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -66,11 +67,15 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const rb_gpu_triangle* __res
             mx[a] = fmaxf(t.v0[a], fmaxf(t.v1[a], t.v2[a]));
             cn[a] = cx[a] = 0.5f * (mn[a] + mx[a]);
         }
-        // as the host builder: q = L^2 / N (L the longer edge at v0, N = |e1 x e2|); its largest value below a
-        // child scales that child's culling margin (FastWalk::entry).  N = 0: +inf (the child is always entered)
+        // F_k as the host builder's tri_bound (rb_bvh.cpp), with the host's small / large decision (slot_meta): a
+        // small triangle's bound L^2 / 1e-6 covers all its hits, a large one's (L^2 / N) / (0.95 c0) those with
+        // |cos| >= c0.  Its largest value below a child scales that child's culling margin (FastWalk::entry).
         const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-        const double nn = sqrt(nx * nx + ny * ny + nz * nz);
-        const float q = (nn > 0.0 && nn < 1e300) ? static_cast<float>(fmax(l1, l2) / nn * 1.000001) : inf;
+        const double nn = sqrt(nx * nx + ny * ny + nz * nz), ll = fmax(l1, l2);
+        const bool large = (slot_meta[(size_t)slots[i] * 2u + 1u] & kSlotLarge) != 0u;
+        float q = inf;
+        if (!large) q = static_cast<float>(ll * 1e6 * (1.0 + 1e-5) * (1.0 + 1e-6));
+        else if (nn > 0.0 && nn < 1e300) q = static_cast<float>(ll / nn / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5));
         pmin[i] = make_float4(mn[0], mn[1], mn[2], q);
         pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
     }
@@ -175,15 +180,13 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long
     if (i == 0) parent[0] = 0u;
 }
 
-// FA of a child from the largest q below it (rb_device_intersect.hpp, FastWalk::entry): q / (0.95 c0), +inf
-// (always enter) when no finite bound exists or beyond the range the bound is claimed for
-__device__ __forceinline__ uint32_t fa_bits(float q) {
-    float fa = q / (0.95f * kFastGrazeCos) * (1.0f + 1e-4f);
-    if (!(fa <= 1.5e5f)) fa = __builtin_inff();
-    return __float_as_uint(fa);
+// FA of a child = the largest F_k below it (rb_device_intersect.hpp, FastWalk::entry); +inf (always enter) when
+// no finite bound exists or beyond the range the bound is claimed for
+__device__ __forceinline__ uint32_t fa_bits(float f) {
+    return __float_as_uint((f <= 1.5e5f) ? f : __builtin_inff());
 }
 
-// nmin[i] = {box min, largest q below}, nmax[i] = {box max, height as uint bits}.
+// nmin[i] = {box min, largest F_k below}, nmax[i] = {box max, height as uint bits}.
 __global__ void __launch_bounds__(256) k_lbvh_refit(const uint32_t* __restrict__ items, uint32_t n,
                                                      const float4* __restrict__ pmin, const float4* __restrict__ pmax,
                                                      const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t* __restrict__ 
 constexpr int kPlocRadius = RB_PLOC_RADIUS;
 
 struct PlocClusters {
-    float4* lo;      // box min, largest q = L^2 / N below
+    float4* lo;      // box min, largest F_k below
     float4* hi;      // box max, height (uint bits)
     uint32_t* ref;   // child reference a parent would store
     uint32_t* run;   // single triangle: its position in the Morton order; otherwise ~0
@@ -421,8 +424,8 @@ inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
 
 // All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream_,
-                          bool plain_lbvh) {
+                          const uint32_t* slot_meta, SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out,
+                          void* stream_, bool plain_lbvh) {
     if (n < 2u || n >= (1u << 28)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using key_t = unsigned long long;
@@ -485,7 +488,7 @@ int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, 
     if (e != hipSuccess) return done(e);
     e = hipMemsetAsync(flags, 0, 4u * n, stream);
     if (e != hipSuccess) return done(e);
-    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, n, pmin, pmax, bounds);
+    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, stream, tris, indices, slots, slot_meta, n, pmin, pmax, bounds);
     hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, stream, pmin, pmax, n, bounds, keys_in, items_in);
     e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_in, keys, items_in, items, n, 0, 63, stream);
     if (e != hipSuccess) return done(e);

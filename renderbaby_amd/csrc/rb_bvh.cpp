@@ -256,20 +256,25 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
 // Moller-Trumbore can report a hit some distance away from the triangle: at most
 // 26 u (|s| + L) L^2 / |a| + ... (rb_device_intersect.hpp, FastWalk::entry).  Two things
 // are made here for that, rounded outwards:
-//   per child of the library's tree  FA = max_k (L_k^2 / N_k) / (0.95 c0)  (L = longer of the two edges at v0,
-//       N = |e1 x e2|, c0 = kFastGrazeCos): scales the margin that covers every hit with |cos(ray, normal)| >= c0;
+//   per child of the library's tree  FA = the largest F_k below it, F_k bounding L_k^2 / |a^| over the hits of
+//       triangle k that the tree's walk answers for (L = longer of the two edges at v0, N = |e1 x e2|):
+//         "small" k (L_k^2 / 1e-6 <= kFastSmallCap): F_k = L_k^2 / 1e-6 -- the reference accepts no |a^| < 1e-6, so
+//                 this covers EVERY accepted hit of k;
+//         "large" k: F_k = (L_k^2 / N_k) / (0.95 c0), c0 = kFastGrazeCos -- covers its hits with
+//                 |cos(ray, normal)| >= c0;
 //       +inf (always enter) beyond 1.5e5 or when a triangle below has N = 0;
-//   per node of the REFERENCE tree  a cone {c cos(alpha), tan(alpha)} that contains every triangle normal below
-//       it (either orientation): the hits with |cos| < c0 -- a ray within ~1.7 degrees of the triangle's plane,
-//       where no useful bound exists -- are found by a second walk over the reference's own tree that only
-//       enters nodes whose cone admits such a triangle (FastWalk::graze_pass).
+//   per node of the REFERENCE tree  a cone {c cos(alpha), tan(alpha)} that contains the normal of every LARGE
+//       triangle below it (either orientation): their hits with |cos| < c0 -- a ray within ~1.7 degrees of the
+//       triangle's plane, where no useful bound exists -- are found by a second walk over the reference's own
+//       tree that only enters nodes whose cone admits such a triangle (FastWalk::gnode_step / gleaf_step).  A
+//       mesh of small triangles has no such node at all.
 namespace {
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct FBuilder {
     const std::vector<float>& bmn;   // per item: tight box min (3 floats)
     const std::vector<float>& bmx;
-    const std::vector<float>& q;     // per item: L^2 / N (+inf if N == 0)
+    const std::vector<float>& q;     // per item: F_k (see above; +inf if N == 0)
     std::vector<uint32_t>& items;    // permuted in place
     std::vector<SphereNode>& nodes;
     uint32_t limit;
@@ -293,8 +298,7 @@ struct FBuilder {
     float fa(size_t first, size_t count) const {
         float m = 0.0f;
         for (size_t i = first; i < first + count; ++i) m = std::max(m, q[items[i]]);
-        const double f = double(m) / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5);   // 0.95: |a^| >= 0.95 |a| in the bound's range
-        return (f <= 1.5e5) ? static_cast<float>(f) : kInf;
+        return (m <= 1.5e5f) ? m : kInf;
     }
     static float area(const float mn[3], const float mx[3]) {
         const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
@@ -417,6 +421,31 @@ struct FBuilder {
 };
 }  // namespace
 
+// F_k of one triangle and whether it is "large" (see the comment above FBuilder), from the f32 edges the kernels
+// use.  The device builder gets the flag from slot_meta and repeats the arithmetic in double (rb_build.hip).
+TriBound tri_bound(const rb_gpu_triangle& t) {
+    double e1[3], e2[3], l1 = 0, l2 = 0;
+    for (int a = 0; a < 3; ++a) {
+        e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
+        e2[a] = double(t.v2[a] - t.v0[a]);
+        l1 += e1[a] * e1[a];
+        l2 += e2[a] * e2[a];
+    }
+    TriBound b;
+    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz), ll = std::max(l1, l2);
+    const double cap = ll * 1e6 * (1.0 + 1e-5);   // L^2 / fl(1e-6), rounded up
+    b.has_normal = nn > 0.0 && std::isfinite(nn);
+    if (b.has_normal) {
+        b.n[0] = nx / nn; b.n[1] = ny / nn; b.n[2] = nz / nn;
+    }
+    b.large = !(cap <= double(kFastSmallCap));
+    if (!b.large) b.f = static_cast<float>(cap * (1.0 + 1e-6));
+    else if (b.has_normal) b.f = static_cast<float>(ll / nn / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5));   // 0.95: |a^| >= 0.95 |a| in the bound's range
+    else b.f = std::numeric_limits<float>::infinity();
+    return b;
+}
+
 namespace {
 // cone of unit normals: axis c, half-angle alpha; `valid` false = "no useful cone" (wider than ~89 degrees)
 struct DCone {
@@ -463,8 +492,10 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 if (slot >= index_len) continue;                     // guard :331
                 if (indices[slot] >= tri_count) { ++rank; continue; }  // guard :336
                 if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the reference walk
+                const bool large = tri_bound(tris[indices[slot]]).large;
                 out.slot_meta[slot * 2] = ni;
-                out.slot_meta[slot * 2 + 1] = rank++;
+                out.slot_meta[slot * 2 + 1] = rank++ | (large ? kSlotLarge : 0u);
+                out.n_large += large ? 1u : 0u;
                 slots.push_back(slot);
             }
         } else {
@@ -481,22 +512,17 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         const rb_bvh_node& n = ref_nodes[ni];
         DCone c;
         if (n.primitive_count > 0) {
-            // direct: axis = normalised sum of the sign-aligned normals, alpha = largest angle to it
+            // direct, over the LARGE triangles of the leaf: axis = normalised sum of the sign-aligned normals,
+            // alpha = largest angle to it
             std::vector<std::array<double, 3>> nrm;
             bool ok = true;
             for (uint32_t i = 0; i < n.primitive_count && ok; ++i) {
                 const uint32_t slot = n.first_primitive + i;
                 if (slot >= index_len || indices[slot] >= tri_count) continue;
-                const rb_gpu_triangle& t = tris[indices[slot]];
-                double e1[3], e2[3];
-                for (int a = 0; a < 3; ++a) {
-                    e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
-                    e2[a] = double(t.v2[a] - t.v0[a]);
-                }
-                const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
-                if (!(nn > 0.0) || !std::isfinite(nn)) { ok = false; break; }   // no normal: any direction "grazes" it
-                nrm.push_back({nx / nn, ny / nn, nz / nn});
+                const TriBound b = tri_bound(tris[indices[slot]]);
+                if (!b.large) continue;
+                if (!b.has_normal) { ok = false; break; }   // no normal: any direction "grazes" it
+                nrm.push_back({b.n[0], b.n[1], b.n[2]});
             }
             if (ok && nrm.empty()) {   // nothing testable below: never needs a visit (alpha = 0 around any axis)
                 c.valid = true; c.alpha = -1.0; c.c[0] = 1.0;   // alpha < 0 marks "empty" for the merges above it
@@ -565,16 +591,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
         const rb_gpu_triangle& t = tris[indices[slots[i]]];
-        double l1 = 0, l2 = 0, e1[3], e2[3];
-        for (int a = 0; a < 3; ++a) {
-            e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
-            e2[a] = double(t.v2[a] - t.v0[a]);
-            l1 += e1[a] * e1[a];
-            l2 += e2[a] * e2[a];
-        }
-        const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-        const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
-        q[i] = (nn > 0.0 && std::isfinite(nn)) ? static_cast<float>(std::max(l1, l2) / nn * 1.000001) : kInf;
+        q[i] = tri_bound(t).f;
         for (int a = 0; a < 3; ++a) {
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));

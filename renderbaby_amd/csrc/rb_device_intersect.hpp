@@ -403,6 +403,8 @@ struct FastWalk {
         uint32_t slot = cur & 0x7FFFFFFFu;
         const uint32_t stop = (slot + kGrazeChunk < gend) ? slot + kGrazeChunk : gend;
         for (; slot < stop; slot++) {
+            const uint32_t rank_word = meta[slot * 2u + 1u];
+            if ((rank_word & kSlotLarge) == 0u) continue;   // a small triangle: the first pass answers for all its hits
             const v4f nr = ptris[slot * 4u + 3u];
             // prepared normal vs true normal: the f32 cross product is off by <= 2.42 u L^2, i.e. the direction by
             // <= 2.5 u q + 3 u <= 6.5e-4 rad for every triangle (A) has a finite margin for (q <= 4275); a
@@ -414,7 +416,7 @@ struct FastWalk {
             float u, v;
             const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
             if (t > 0.001f && !(t > h.t)) {
-                const uint32_t rank = meta[slot * 2u + 1u];
+                const uint32_t rank = rank_word & ~kSlotLarge;
                 if (t < h.t || rank < best_rank) {
                     h.hit = true;
                     h.t = t;
@@ -514,7 +516,7 @@ struct FastWalk {
             const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
             if (t > 0.001f && !(t > h.t)) {
                 const uint32_t slot = fslots[j];
-                const uint32_t leaf_node = meta[slot * 2u], rank = meta[slot * 2u + 1u];
+                const uint32_t leaf_node = meta[slot * 2u], rank = meta[slot * 2u + 1u] & ~kSlotLarge;
                 if ((t < h.t || rank < best_rank) && reference_would_test(p, leaf_node, tl)) {
                     h.hit = true;
                     h.t = t;

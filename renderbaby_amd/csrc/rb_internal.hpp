@@ -49,6 +49,11 @@ constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the librar
 // |cos(ray, triangle normal)| >= c0 are covered by the culling margin of the library's tree (FA in each node's two
 // pad words), the others by a second pass over the reference tree guided by per-node normal cones.
 constexpr float kFastGrazeCos = 0.03f;
+// A triangle whose determinant bound L^2 / 1e-6 (the reference rejects |a^| < 1e-6) is at most this is "small": the
+// culling margin of the library's tree then covers ALL its accepted hits, near-degenerate ones included, and the
+// second pass skips it.  1500 <=> L <= 0.039: a margin of at most 2.4e-3 of the distance to the box.
+constexpr float kFastSmallCap = 1500.0f;
+constexpr uint32_t kSlotLarge = 0x80000000u;   // slot_meta[2 * slot + 1]: bit 31 = "large" triangle, low bits = reference rank
 // A node of the reference tree as that second pass reads it: the caller's box and links bit for bit (the pass
 // repeats the reference's own slab test), plus the cone {axis cos(alpha), tan(alpha)} of the triangle normals below.
 struct alignas(16) GrazeNode {
@@ -61,10 +66,18 @@ struct alignas(16) GrazeNode {
 };
 static_assert(sizeof(GrazeNode) == 64, "GrazeNode is 64 B");
 
+struct TriBound {
+    double n[3] = {0, 0, 0};   // unit normal (if has_normal)
+    float f = 0.0f;            // F_k: bound of L^2 / |a^| over the hits the library's tree answers for
+    bool large = false, has_normal = false;
+};
+TriBound tri_bound(const rb_gpu_triangle& t);
+
 // The library's own triangle tree (rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
 struct FastTree {
     std::vector<SphereNode> nodes;
     std::vector<GrazeNode> gnodes;     // per REFERENCE node: its box, links and the cone of the normals below it
+    uint32_t n_large = 0;              // triangles the second pass answers for ("large", rb_bvh.cpp)
     std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
     std::vector<uint32_t> ref_parent;  // reference tree: parent of each node (root: 0)
@@ -87,8 +100,8 @@ struct DeviceTreeInfo {
     float bmin[3], bmax[3];
 };
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,
-                          SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out, void* stream,
-                          bool plain_lbvh);
+                          const uint32_t* slot_meta, SphereNode* nodes_out, uint32_t* fast_slots_out, DeviceTreeInfo* info_out,
+                          void* stream, bool plain_lbvh);
 
 // ---- device-side counters (one block of u64 in device memory)
 enum Counter : uint32_t {

@@ -541,6 +541,15 @@ int ensure_prepared(rb_engine* e) {
         const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
         bool built = false;
         e->fast_builder = "";
+        // The library's tree answers for every hit of a "small" triangle but only for the well-conditioned hits of a
+        // "large" one (rb_bvh.cpp); the rest needs a second pass over the reference tree that costs about as much as
+        // the reference walk's node phase.  Unless the caller asked for the library's tree, a mesh made mostly of
+        // large triangles keeps the reference walk.
+        if (!(e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH))) {
+            size_t large = 0;
+            for (uint32_t i = 0; i < n_tris; ++i) large += rb::tri_bound(e->host_tris[i]).large ? 1u : 0u;
+            if (large * 4 > n_tris) return RB_OK;
+        }
         // which builder: the device one from kDeviceBuildMinTriangles up (milliseconds instead of ~0.15 s per
         // million triangles), the host's binned SAH below; either can be forced
         const bool force_host = (e->opt.flags & RB_FLAG_HOST_BVH) != 0u, force_dev = (e->opt.flags & RB_FLAG_DEVICE_BVH) != 0u;
@@ -552,11 +561,12 @@ int ensure_prepared(rb_engine* e) {
                 const uint32_t n = static_cast<uint32_t>(ft.slots.size());
                 DevBuf<uint32_t> visit_slots;
                 rc = upload(e, visit_slots, ft.slots.data(), ft.slots.size(), nullptr, true);
+                if (!rc) rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
                 if (rc) return rc;
                 HIP_TRY(e, e->fast_nodes.resize(n - 1));
                 HIP_TRY(e, e->fast_slots.resize(n));
                 rb::DeviceTreeInfo info{};
-                rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->fast_nodes.ptr,
+                rc = rb::device_fast_bvh_build(e->tris.ptr, e->indices.ptr, visit_slots.ptr, n, e->slot_meta.ptr, e->fast_nodes.ptr,
                                                e->fast_slots.ptr, &info, e->stream, (e->opt.flags & RB_FLAG_DEVICE_LBVH) != 0u);
                 if (rc && rc != static_cast<int>(hipErrorNotReady))
                     return fail(e, RB_ERR_DEVICE, "device BVH build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));

@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--stripe-rows", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.algorithmic = null)")
+    ap.add_argument("--skip-near-degenerate", action="store_true", help="RB_FLAG_SKIP_NEAR_DEGENERATE (the one unproved mode)")
     ap.add_argument("--walk", default="", choices=["", "reference", "own", "own-host", "own-device"],
                     help="multi-node meshes: the reference walk or the library's own tree (default: the library's default)")
     ap.add_argument("--fast-bvh", action="store_true", help="same as --walk own-host")
@@ -221,7 +222,7 @@ def main():
 
     scene, desc = make_scene(a.workload, a.spp)
     spp = scene.total_samples
-    wkw = walk_kwargs(a.walk)
+    wkw = dict(walk_kwargs(a.walk), skip_near_degenerate=a.skip_near_degenerate)
 
     def barrier():
         if world > 1:
@@ -279,7 +280,7 @@ def main():
         k_ms = trace_ms_step / launches
         seg_rate = seg_per_step / (trace_ms_step * 1e-3) if trace_ms_step > 0 else 0.0   # this rank's segments/s inside the trace kernel
         fingerprint = _lib.source_fingerprint()
-        key = a.workload + ("" if not a.walk else "_" + a.walk.replace("-", ""))
+        key = a.workload + ("" if not a.walk else "_" + a.walk.replace("-", "")) + ("_skip" if a.skip_near_degenerate else "")
         pmc, pmc_note = load_pmc(key, kernel_name, fingerprint)
         roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "kernel": kernel_name + "<false>", "kernel_ms": k_ms, "launches_per_step": launches,

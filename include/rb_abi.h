@@ -242,7 +242,12 @@ enum {
     RB_FLAG_HOST_BVH = 64u, /* build the library's tree on the host (binned SAH) whatever the triangle count */
     RB_FLAG_GATHER_PEER_COPY = 128u, /* rb_create_multi: move the stripes with hipMemcpyPeerAsync instead of RCCL
                                         (hosts without librccl; several shards on one device in the tests) */
-    RB_FLAG_NO_RUN_AHEAD = 256u /* progressive iterator: do not start the next pass while a frame is read back */
+    RB_FLAG_NO_RUN_AHEAD = 256u, /* progressive iterator: do not start the next pass while a frame is read back */
+    RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
+                                           hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
+                                           (L^2 > 1.5e-3); a hit the reference reports from a near-zero determinant there can be
+                                           missed.  Several times faster on coarse meshes; frames validated equal on the
+                                           BASELINE scenes, but this is the one mode that is not proved exact. */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.

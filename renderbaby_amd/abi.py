@@ -69,6 +69,7 @@ FLAG_REFERENCE_WALK = 32
 FLAG_HOST_BVH = 64
 FLAG_GATHER_PEER_COPY = 128
 FLAG_NO_RUN_AHEAD = 256
+FLAG_SKIP_NEAR_DEGENERATE = 512
 COMM_ID_BYTES = 128
 
 

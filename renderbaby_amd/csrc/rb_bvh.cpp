@@ -568,7 +568,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         const DCone& c = cones[ni];
         float* o = g.cone;   // all zeros = "always possible"
         if (!c.valid) continue;
-        if (c.alpha < 0.0) continue;   // nothing testable below: left as "always possible" (a wasted visit at worst)
+        if (c.alpha < 0.0) { o[3] = -1.0f; continue; }   // no large triangle below: tan = -1 tells the walk never to enter
         const double cos_a = std::cos(c.alpha) * (1.0 - 1e-6) - 1e-7;
         if (!(cos_a > 0.0175)) continue;
         const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));

@@ -318,7 +318,7 @@ struct FastWalk {
     // false when both are complete
     DEV bool pop(const KParams& p, const uint32_t* stack, uint32_t stride) {
         if (sp == 0) {
-            if (graze) return false;
+            if (graze || p.fast_skip_second_pass != 0u) return false;
             graze = true;
             cur = 0u;
             return true;
@@ -347,8 +347,10 @@ struct FastWalk {
 
     // (B): can a triangle with |cos(d, n)| < c0 lie below a reference node?  cone = {c cos(alpha), tan(alpha)},
     // every unit normal below is within alpha of +-c, so |cos(d, n)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with
-    // x = |d . c|.  y = x cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible.
+    // x = |d . c|.  y = x cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible;
+    // tan(alpha) = -1 = no large triangle below = never.
     DEV bool graze_possible(v4f cone) const {
+        if (cone.w < 0.0f) return false;   // no large triangle below this node
         const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
         const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
         const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);

@@ -146,6 +146,7 @@ struct KParams {
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
     const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
     const GrazeNode* gnodes;       // per reference node: box, links, normal cone (the walk's second pass)
+    uint32_t fast_skip_second_pass; // RB_FLAG_SKIP_NEAR_DEGENERATE
     const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
     const uint32_t* fast_slots;    // fast-leaf order -> slot
     const uint32_t* slot_meta;     // per slot {reference leaf node, reference rank}

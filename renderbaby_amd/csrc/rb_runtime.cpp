@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -665,6 +666,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
     p.gnodes = e->gnodes.ptr;
+    p.fast_skip_second_pass = (e->opt.flags & RB_FLAG_SKIP_NEAR_DEGENERATE) ? 1u : 0u;
     p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
     p.fast_slots = e->fast_slots.ptr;
     p.slot_meta = e->slot_meta.ptr;

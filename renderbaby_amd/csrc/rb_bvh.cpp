@@ -451,9 +451,11 @@ namespace {
 struct DCone {
     double c[3] = {0, 0, 0}, alpha = 4.0;
     bool valid = false;
+    double cap = 0.0;   // largest L^2 / 1e-6 over the large triangles below
 };
 DCone merge(const DCone& a, const DCone& b_) {
     DCone out;
+    out.cap = std::max(a.cap, b_.cap);
     if (!a.valid || !b_.valid) return out;
     DCone b = b_;
     if (a.c[0] * b.c[0] + a.c[1] * b.c[1] + a.c[2] * b.c[2] < 0.0)
@@ -464,7 +466,7 @@ DCone merge(const DCone& a, const DCone& b_) {
     for (double& x : s) x /= len;
     auto ang = [&](const double v[3]) { return std::acos(std::min(1.0, std::max(-1.0, s[0] * v[0] + s[1] * v[1] + s[2] * v[2]))); };
     out.alpha = std::max(ang(a.c) + a.alpha, ang(b.c) + b.alpha) + 1e-9;
-    if (!(out.alpha < 1.55)) return DCone{};
+    if (!(out.alpha < 1.55)) { DCone bad; bad.cap = out.cap; return bad; }
     for (int i = 0; i < 3; ++i) out.c[i] = s[i];
     out.valid = true;
     return out;
@@ -507,11 +509,13 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
     // ---- per reference node: the cone of the triangle normals below it (bottom-up: leaves from their triangles,
     // inner nodes by merging their children's cones), for the walk's second pass over near-degenerate hits
     std::vector<DCone> cones(node_count);
+    std::vector<std::pair<uint32_t, uint32_t>> grange(node_count, {0u, 0u});
     for (size_t k = order.size(); k-- > 0;) {
         const uint32_t ni = order[k];
         const rb_bvh_node& n = ref_nodes[ni];
         DCone c;
         if (n.primitive_count > 0) {
+            grange[ni].first = static_cast<uint32_t>(out.gslots.size());
             // direct, over the LARGE triangles of the leaf: axis = normalised sum of the sign-aligned normals,
             // alpha = largest angle to it
             std::vector<std::array<double, 3>> nrm;
@@ -519,12 +523,21 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             for (uint32_t i = 0; i < n.primitive_count && ok; ++i) {
                 const uint32_t slot = n.first_primitive + i;
                 if (slot >= index_len || indices[slot] >= tri_count) continue;
-                const TriBound b = tri_bound(tris[indices[slot]]);
+                const rb_gpu_triangle& t = tris[indices[slot]];
+                const TriBound b = tri_bound(t);
                 if (!b.large) continue;
-                if (!b.has_normal) { ok = false; break; }   // no normal: any direction "grazes" it
+                out.gslots.push_back(slot);
+                double l1 = 0, l2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    l1 += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);
+                    l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
+                }
+                c.cap = std::max(c.cap, std::max(l1, l2) * 1e6 * (1.0 + 1e-5));
+                if (!b.has_normal) { ok = false; continue; }   // no normal: any direction "grazes" it
                 nrm.push_back({b.n[0], b.n[1], b.n[2]});
             }
-            if (ok && nrm.empty()) {   // nothing testable below: never needs a visit (alpha = 0 around any axis)
+            grange[ni].second = static_cast<uint32_t>(out.gslots.size()) - grange[ni].first;
+            if (ok && nrm.empty()) {   // no large triangle in this leaf: never needs a visit
                 c.valid = true; c.alpha = -1.0; c.c[0] = 1.0;   // alpha < 0 marks "empty" for the merges above it
             } else if (ok) {
                 double sum[3] = {0, 0, 0};
@@ -548,6 +561,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 if (a.valid && a.alpha < 0.0) c = b;          // an empty side adds nothing
                 else if (b.valid && b.alpha < 0.0) c = a;
                 else c = merge(a, b);
+                c.cap = std::max(a.cap, b.cap);
             } else if (hl) c = cones[n.left];
             else if (hr) c = cones[n.right];
             else { c.valid = true; c.alpha = -1.0; c.c[0] = 1.0; }
@@ -563,9 +577,11 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         std::memcpy(g.bmax, n.aabb_max, 12);
         g.left = n.left;
         g.right = n.right;
-        g.first = n.first_primitive;
-        g.count = n.primitive_count;
+        g.is_leaf = n.primitive_count > 0 ? 1u : 0u;
+        g.first = grange[ni].first;
+        g.count = grange[ni].second;
         const DCone& c = cones[ni];
+        g.cap = (c.cap <= 1.5e5) ? static_cast<float>(c.cap * (1.0 + 1e-6)) : std::numeric_limits<float>::infinity();
         float* o = g.cone;   // all zeros = "always possible"
         if (!c.valid) continue;
         if (c.alpha < 0.0) { o[3] = -1.0f; continue; }   // no large triangle below: tan = -1 tells the walk never to enter

@@ -372,27 +372,33 @@ struct FastWalk {
             const v4f n0 = gn[0], n1 = gn[1];
             if constexpr (STATS) tl.nodes++;
             if (isect_aabb(o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
-                const v4u n3 = ((cu4p)gn)[3];
-                const uint32_t node_count = p.u.bvh_node_count;
-                if (n3.y > 0u) {   // leaf: scan [first, first + count) below index_len (guard :331)
-                    const uint32_t end = (n3.x + n3.y < p.index_len) ? n3.x + n3.y : p.index_len;
-                    if (n3.x < end) {
-                        cur = 0x80000000u | n3.x;
-                        gend = end;
-                        return true;
-                    }
-                } else {
-                    const uint32_t l = __float_as_uint(n0.w), r = __float_as_uint(n1.w);
-                    const bool hl = l < node_count, hr = r < node_count;   // guards :376-387
-                    if (hl && hr) {
-                        stack[sp * stride] = r;
-                        sp++;
-                        cur = l;
-                        return true;
-                    }
-                    if (hl || hr) {
-                        cur = hl ? l : r;
-                        return true;
+                const v4f n3 = gn[3];   // first, count (the leaf's large triangles in gslots), cap, is_leaf
+                // A near-degenerate hit of a triangle below is reported no farther than margin(cap) from this box
+                // (entry(): the same bound with L^2 / |a^| <= L^2 / 1e-6), so it cannot beat the best t if the ray
+                // enters the inflated box beyond it.
+                float tn;
+                if (entry(n0, n1, n3.z, tn)) {
+                    const uint32_t node_count = p.u.bvh_node_count;
+                    if (__float_as_uint(n3.w) != 0u) {   // leaf
+                        const uint32_t first = __float_as_uint(n3.x), count = __float_as_uint(n3.y);
+                        if (count > 0u) {
+                            cur = 0x80000000u | first;
+                            gend = first + count;
+                            return true;
+                        }
+                    } else {
+                        const uint32_t l = __float_as_uint(n0.w), r = __float_as_uint(n1.w);
+                        const bool hl = l < node_count, hr = r < node_count;   // guards :376-387
+                        if (hl && hr) {
+                            stack[sp * stride] = r;
+                            sp++;
+                            cur = l;
+                            return true;
+                        }
+                        if (hl || hr) {
+                            cur = hl ? l : r;
+                            return true;
+                        }
                     }
                 }
             }
@@ -402,11 +408,11 @@ struct FastWalk {
     DEV bool gleaf_step(const KParams& p, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
         const cf4p ptris = (cf4p)p.ptris;
         const RB_CONST uint32_t* meta = cptr(p.slot_meta);
-        uint32_t slot = cur & 0x7FFFFFFFu;
-        const uint32_t stop = (slot + kGrazeChunk < gend) ? slot + kGrazeChunk : gend;
-        for (; slot < stop; slot++) {
-            const uint32_t rank_word = meta[slot * 2u + 1u];
-            if ((rank_word & kSlotLarge) == 0u) continue;   // a small triangle: the first pass answers for all its hits
+        const RB_CONST uint32_t* gslots = cptr(p.gslots);
+        uint32_t j = cur & 0x7FFFFFFFu;
+        const uint32_t stop = (j + kGrazeChunk < gend) ? j + kGrazeChunk : gend;
+        for (; j < stop; j++) {
+            const uint32_t slot = gslots[j];
             const v4f nr = ptris[slot * 4u + 3u];
             // prepared normal vs true normal: the f32 cross product is off by <= 2.42 u L^2, i.e. the direction by
             // <= 2.5 u q + 3 u <= 6.5e-4 rad for every triangle (A) has a finite margin for (q <= 4275); a
@@ -418,7 +424,7 @@ struct FastWalk {
             float u, v;
             const float t = isect_triangle(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), u, v);
             if (t > 0.001f && !(t > h.t)) {
-                const uint32_t rank = rank_word & ~kSlotLarge;
+                const uint32_t rank = meta[slot * 2u + 1u] & ~kSlotLarge;
                 if (t < h.t || rank < best_rank) {
                     h.hit = true;
                     h.t = t;
@@ -430,8 +436,8 @@ struct FastWalk {
                 }
             }
         }
-        if (slot < gend) {
-            cur = 0x80000000u | slot;
+        if (j < gend) {
+            cur = 0x80000000u | j;
             return true;
         }
         return pop(p, stack, stride);

@@ -62,7 +62,10 @@ struct alignas(16) GrazeNode {
     float bmax[3];
     uint32_t right;
     float cone[4];
-    uint32_t first, count, _pad[2];
+    uint32_t first, count;   // leaf: range in FastTree::gslots (the leaf's LARGE triangles only)
+    float cap;               // largest L^2 / 1e-6 over the large triangles below (+inf beyond 1.5e5): bounds how far from the
+                             // node's box a near-degenerate hit can be reported, so the pass can cull on the best t
+    uint32_t is_leaf;
 };
 static_assert(sizeof(GrazeNode) == 64, "GrazeNode is 64 B");
 
@@ -77,6 +80,7 @@ TriBound tri_bound(const rb_gpu_triangle& t);
 struct FastTree {
     std::vector<SphereNode> nodes;
     std::vector<GrazeNode> gnodes;     // per REFERENCE node: its box, links and the cone of the normals below it
+    std::vector<uint32_t> gslots;      // the large triangles' slots, leaf by leaf (GrazeNode::first / count)
     uint32_t n_large = 0;              // triangles the second pass answers for ("large", rb_bvh.cpp)
     std::vector<uint32_t> slots;       // leaf order -> slot in bvh_indices order
     std::vector<uint32_t> slot_meta;   // per slot: {reference leaf node, rank in the reference visit order}
@@ -146,6 +150,7 @@ struct KParams {
     const float* srgb_lut;         // 256 entries: powf(i/255, 2.2) computed on the host
     const SphereNode* fast_nodes;  // fast triangle tree (nullptr => the reference walk)
     const GrazeNode* gnodes;       // per reference node: box, links, normal cone (the walk's second pass)
+    const uint32_t* gslots;        // slots of the large triangles, leaf by leaf
     uint32_t fast_skip_second_pass; // RB_FLAG_SKIP_NEAR_DEGENERATE
     const float* fast_tris;        // PrepTri records gathered into fast-leaf order (64 B each)
     const uint32_t* fast_slots;    // fast-leaf order -> slot

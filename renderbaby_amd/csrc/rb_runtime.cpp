@@ -124,6 +124,7 @@ struct rb_engine {
     DevBuf<rb::PrepTri> fast_tris;
     DevBuf<uint32_t> fast_slots, slot_meta, ref_parent, stack_overflow;
     DevBuf<rb::GrazeNode> gnodes;
+    DevBuf<uint32_t> gslots;
     uint32_t fast_root = 0, fast_depth = 0;
     float fast_margin = 0.0f, fast_root_amax = 0.0f;
     float fast_bmin[3] = {0, 0, 0}, fast_bmax[3] = {0, 0, 0};
@@ -549,7 +550,7 @@ int ensure_prepared(rb_engine* e) {
         if (!(e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH))) {
             size_t large = 0;
             for (uint32_t i = 0; i < n_tris; ++i) large += rb::tri_bound(e->host_tris[i]).large ? 1u : 0u;
-            if (large * 4 > n_tris) return RB_OK;
+            if (large * 20 > n_tris) return RB_OK;
         }
         // which builder: the device one from kDeviceBuildMinTriangles up (milliseconds instead of ~0.15 s per
         // million triangles), the host's binned SAH below; either can be forced
@@ -607,6 +608,7 @@ int ensure_prepared(rb_engine* e) {
         rc = upload(e, e->slot_meta, ft.slot_meta.data(), ft.slot_meta.size(), nullptr, true);
         if (!rc) rc = upload(e, e->ref_parent, ft.ref_parent.data(), ft.ref_parent.size(), nullptr, true);
         if (!rc) rc = upload(e, e->gnodes, ft.gnodes.data(), ft.gnodes.size(), nullptr, true);
+        if (!rc) rc = upload(e, e->gslots, ft.gslots.data(), ft.gslots.size(), nullptr, true);
         if (rc) return rc;
         const size_t n_items = e->fast_slots.count;
         HIP_TRY(e, e->fast_tris.resize(n_items));
@@ -666,6 +668,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
     p.gnodes = e->gnodes.ptr;
+    p.gslots = e->gslots.ptr;
     p.fast_skip_second_pass = (e->opt.flags & RB_FLAG_SKIP_NEAR_DEGENERATE) ? 1u : 0u;
     p.fast_tris = reinterpret_cast<const float*>(e->fast_tris.ptr);
     p.fast_slots = e->fast_slots.ptr;

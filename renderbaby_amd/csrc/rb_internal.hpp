@@ -38,9 +38,11 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
                       float bmax[3]);
 
 // Walk mode of multi-node meshes when the caller's flags do not say: the library's own tree (true) or the
-// reference walk (false).  RB_FLAG_REFERENCE_WALK / RB_FLAG_FAST_BVH override it per engine.
+// reference walk (false).  RB_FLAG_REFERENCE_WALK / RB_FLAG_FAST_BVH override it per engine.  The proved form of
+// the library's walk needs a second pass for near-degenerate hits that costs about as much as the reference
+// walk's node phase, so it does not beat the reference walk on the BASELINE meshes: off.
 #ifndef RB_FAST_WALK_DEFAULT
-#define RB_FAST_WALK_DEFAULT 1
+#define RB_FAST_WALK_DEFAULT 0
 #endif
 constexpr bool kFastWalkByDefault = RB_FAST_WALK_DEFAULT != 0;
 constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the library's tree is built on the device by default

@@ -543,15 +543,6 @@ int ensure_prepared(rb_engine* e) {
         const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
         bool built = false;
         e->fast_builder = "";
-        // The library's tree answers for every hit of a "small" triangle but only for the well-conditioned hits of a
-        // "large" one (rb_bvh.cpp); the rest needs a second pass over the reference tree that costs about as much as
-        // the reference walk's node phase.  Unless the caller asked for the library's tree, a mesh made mostly of
-        // large triangles keeps the reference walk.
-        if (!(e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH))) {
-            size_t large = 0;
-            for (uint32_t i = 0; i < n_tris; ++i) large += rb::tri_bound(e->host_tris[i]).large ? 1u : 0u;
-            if (large * 20 > n_tris) return RB_OK;
-        }
         // which builder: the device one from kDeviceBuildMinTriangles up (milliseconds instead of ~0.15 s per
         // million triangles), the host's binned SAH below; either can be forced
         const bool force_host = (e->opt.flags & RB_FLAG_HOST_BVH) != 0u, force_dev = (e->opt.flags & RB_FLAG_DEVICE_BVH) != 0u;

@@ -81,21 +81,22 @@ def test_c5_million_triangle_mesh_matches_the_oracle():
     rc = RenderConfig.from_scene(s)
     out = {}
     for mode, kw in (("reference-walk", dict(reference_walk=True)), ("host-sah", dict(host_bvh=True)),
-                     ("device-ploc", dict(device_bvh=True)), ("default", dict())):
+                     ("device-ploc", dict(device_bvh=True)), ("default", dict()),
+                     ("host-sah-skip", dict(host_bvh=True, skip_near_degenerate=True))):
         e = Engine.new(rc, **kw)
         f = e.render(rc)
         out[mode] = (e.read_accumulation(), f.pixels, e.stats()["segments"], e.last_kernel_name())
-        if mode not in ("reference-walk", "default"):
+        if mode in ("host-sah", "device-ploc"):
             assert e.fast_bvh_builder()[0] == mode
-        if mode == "default":   # a mesh of small triangles: the library's own tree, built on the device
-            assert e.fast_bvh_builder()[0] == "device-ploc" and e.last_kernel_name() == "k_trace_fast"
+        if mode == "default":   # the library's default for multi-node meshes is the reference walk
+            assert e.fast_bvh_builder()[0] == "" and e.last_kernel_name() == "k_trace_bvh"
         e.close()
     assert out["reference-walk"][3] == "k_trace_bvh" and out["host-sah"][3] == "k_trace_fast"
     r0, r1 = rows
     for mode, (acc, px, seg, _) in out.items():
         assert np.array_equal(acc[r0:r1].view(np.uint32), o_acc[r0:r1].view(np.uint32)), mode
         assert np.array_equal(px[r0:r1], o_rgba[r0:r1]), mode
-    for mode in ("host-sah", "device-ploc", "default"):
+    for mode in ("host-sah", "device-ploc", "default", "host-sah-skip"):
         diff = (out["reference-walk"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ from the reference walk"
         assert out[mode][2] == out["reference-walk"][2]

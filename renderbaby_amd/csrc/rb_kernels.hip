@@ -338,9 +338,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
 #ifndef RB_BVH_WAVES
 #define RB_BVH_WAVES 1
 #endif
-#ifndef RB_QUAD_FETCH
-#define RB_QUAD_FETCH 1   // the L1/L2 variant fetches triangle records quad-cooperatively (see the leaf phase)
-#endif
 // LDS = true: the whole tree (48 B per node) and the first 48 B of every prepared triangle are
 // first staged into LDS with coalesced 16-byte loads by the whole block, and the walk then reads
 // them with ds_read_b128 instead of going through L1/L2 -- for meshes small enough to fit next to
@@ -460,47 +457,9 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
             }
         }
 
-        // ---- (4) leaf phase: this lane's leaf (shader.wgsl:327-374), two triangles per step; candidates are
-        // offered in slot order
-        if constexpr (!LDS && RB_QUAD_FETCH) {
-            // Every lane is at its own leaf, so a 16-byte load per lane touches 64 different cache lines and the walk
-            // is bound by L1 address processing (three such loads per triangle: profiles/r01_c3_8spp_stream_pmc.json).
-            // Here the four lanes of a quad fetch each other's records instead: in round i all four read the 64-byte
-            // record of quad lane i, 16 bytes each -- one cache line per quad and instruction, 16 lines per wavefront
-            // instead of 64 -- and hand the pieces over through a 4 KiB per-wave exchange buffer in LDS.  Four loads
-            // move what twelve did.  Same records, same tests, same order.
-            const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
-            v4f* const xbuf = reinterpret_cast<v4f*>(s_stack + p.stack_depth * BLOCK) + (size_t)(tid >> 6) * 256u;  // [quad 16][rec 4][part 4]
-            const uint32_t part = lane & 3u, qbase = (lane >> 2) * 16u;
-            uint32_t slot = first;
-            for (;;) {
-                if (__ballot(slot < end) == 0ull) break;
-                v4f rec[2][3];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t mine = slot + (uint32_t)r;
-                    // quad_perm broadcast of quad lane i's slot and end (the DPP control must be a literal)
-#define RB_QUAD_ROUND(i)                                                                                              \
-    {                                                                                                                 \
-        const uint32_t s_i = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, (i) * 0x55, 0xF, 0xF, true);         \
-        const uint32_t e_i = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, (i) * 0x55, 0xF, 0xF, true);          \
-        if (s_i < e_i) xbuf[qbase + (uint32_t)(i) * 4u + part] = ptris[(size_t)s_i * 4u + part];                      \
-    }
-                    RB_QUAD_ROUND(0) RB_QUAD_ROUND(1) RB_QUAD_ROUND(2) RB_QUAD_ROUND(3)
-#undef RB_QUAD_ROUND
-                    __builtin_amdgcn_wave_barrier();   // LDS operations of one wavefront execute in order: only the compiler must not move them
-                    rec[r][0] = xbuf[qbase + part * 4u + 0u];
-                    rec[r][1] = xbuf[qbase + part * 4u + 1u];
-                    rec[r][2] = xbuf[qbase + part * 4u + 2u];
-                    __builtin_amdgcn_wave_barrier();
-                }
-                const bool in0 = slot < end, in1 = slot + 1u < end;
-                const bool ok0 = in0 && __float_as_uint(rec[0][2].w) != 0u, ok1 = in1 && __float_as_uint(rec[1][2].w) != 0u;  // guard :336
-                if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
-                if (in0) test_pair(rec[0][0], rec[0][1], rec[0][2], ok0, rec[1][0], rec[1][1], rec[1][2], ok1, slot, pt.o, pt.d, th, tl);
-                slot = in0 ? slot + 2u : slot;
-            }
-        } else {
+        // ---- (4) leaf phase: this lane's leaf (shader.wgsl:327-374), two triangles per step so
+        // that six 16-byte loads are in flight per lane; candidates are offered in slot order
+        {
             const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
             uint32_t slot = first;
 #if RB_TRI_PAIRS
@@ -1001,9 +960,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph"};
         li.kernel_name = names[v];
         li.block = v == BVH_LDS ? 1024u : kTraceBlock;
-        // the L1/L2 walk adds a 4 KiB per-wave exchange buffer for its quad-cooperative triangle fetches
-        const size_t xbuf_lds = (v == BVH && RB_QUAD_FETCH) ? (size_t)(kTraceBlock / 64u) * 4096u : 0u;
-        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : lds + xbuf_lds;
+        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : lds;
         // residency (registers): k_trace 6 waves/SIMD, the stepped walks 4
         const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : 8u;
         li.grid = persistent_blocks(items, li.block, blocks_per_cu);
@@ -1044,8 +1001,8 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
                 else hipLaunchKernelGGL((k_trace_bvh<false, true, 1024u>), grid, block, li.lds_bytes, stream, q);
                 break;
             case BVH:
-                if (stats) hipLaunchKernelGGL((k_trace_bvh<true, false, kTraceBlock>), grid, block, li.lds_bytes, stream, q);
-                else hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), grid, block, li.lds_bytes, stream, q);
+                if (stats) hipLaunchKernelGGL((k_trace_bvh<true, false, kTraceBlock>), grid, block, lds, stream, q);
+                else hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), grid, block, lds, stream, q);
                 break;
             case PLAIN:
                 if (stats) hipLaunchKernelGGL(k_trace<true>, grid, block, lds, stream, q);

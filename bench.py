@@ -331,7 +331,7 @@ def main():
             "config": {"workload": desc, "width": scene.width, "height": scene.height, "spp": spp,
                        "max_depth": int(scene.uniforms["max_depth"][0]), "segments_per_step": int(seg_total),
                        "paths_per_step": int(paths_total), "Mpaths_per_s": paths_total * a.steps / elapsed / 1e6,
-                       "parallelism": f"row-stripes x{world}, one RCCL gather per frame inside the library" if world > 1 else "single GPU",
+                       "parallelism": f"row-stripes x{world}; {r.gather_note}" if world > 1 else "single GPU",
                        "stripe_rows": a.stripe_rows, "walk": a.walk or "library default",
                        "tree_builder": r.engine.fast_bvh_builder()[0],
                        "device": engine.device_name(local_rank)},

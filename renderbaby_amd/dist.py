@@ -81,13 +81,37 @@ class ShardedRenderer:
         self.engine.update(rc)
         self.width, self.height = scene.width, scene.height
         self.owned, self.padded = shard_layout(self.height, rank, world, stripe_rows)
+        self.gather_note = "torch.distributed gather"
         if self.library_gather:
+            # the communicator id travels by torch.distributed; every rank must agree on whether the library's
+            # RCCL path came up, otherwise all fall back to the torch.distributed gather below
             import torch.distributed as dist
-            box = [Engine.comm_unique_id() if rank == 0 else None]
+            ok, why = 1, ""
+            try:
+                box = [Engine.comm_unique_id() if rank == 0 else None]
+            except Exception as ex:   # librccl not loadable on rank 0
+                box, ok, why = [None], 0, str(ex)
             dist.broadcast_object_list(box, src=0)
-            self.engine.comm_init_rank(box[0], rank, world)
-            self.local = self.gather_list = None
-            return
+            if box[0] is None:
+                ok = 0
+            else:
+                try:
+                    self.engine.comm_init_rank(box[0], rank, world)
+                except Exception as ex:
+                    ok, why = 0, str(ex)
+            flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.gather_note = "one RCCL gather per frame inside librenderbaby_hip.so (rb_comm_init_rank)"
+                self.local = self.gather_list = None
+                return
+            # a rank that did create its communicator keeps rendering its stripes only: start over without it
+            self.library_gather = False
+            self.gather_note = "torch.distributed gather (library RCCL path unavailable: %s)" % (why or "another rank failed")
+            self.engine.close()
+            self.engine = Engine.new(rc, device=device, shard_rank=rank, shard_count=world, stripe_rows=stripe_rows,
+                                     kernel=kernel, passes_per_launch=passes_per_launch, stats=stats, **engine_kw)
+            self.engine.update(rc)
         ptr, nbytes = self.engine.device_rgba()
         rows = self.padded if world > 1 else self.height
         assert nbytes >= rows * self.width * 4

@@ -12,7 +12,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librenderbaby_hip.so")
+# RB_LIBRARY_PATH: an alternative build of the library (A/B experiments with compile-time knobs)
+LIB_PATH = os.environ.get("RB_LIBRARY_PATH") or os.path.join(_HERE, "librenderbaby_hip.so")
 _lib = None
 
 

@@ -457,15 +457,15 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
 }
 
 // One whole iteration of the bounce loop: traversal + everything else.
-template <bool STATS>
+template <bool STATS, bool MULTI = true>
 DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
-    const TriHit th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, stride, tl);
+    const TriHit th = intersect_bvh<STATS, MULTI>(p, pt.o, pt.d, stack, stride, tl);
 #if RB_ABLATE == 1
     {
         f3 o2 = pt.o;
         asm volatile("" : "+v"(o2.x));
         Tally<STATS> t2;
-        const TriHit th2 = intersect_bvh<STATS>(p, o2, pt.d, stack, stride, t2);
+        const TriHit th2 = intersect_bvh<STATS, MULTI>(p, o2, pt.d, stack, stride, t2);
         asm volatile("" ::"v"(th2.t), "v"(th2.slot));
     }
 #endif

@@ -239,7 +239,9 @@ struct ItemQueue {
     }
 };
 
-template <bool STATS>
+// MULTI = false: trees of at most one node only (the default instantiation: launch_render sends every multi-node
+// tree to a stepped kernel); MULTI = true: the per-segment ablation of those (opt no_leaf_stepping).
+template <bool STATS, bool MULTI>
 __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
             continue;
         }
         if (active) {
-            const bool alive = segment<STATS>(p, pt, &s_stack[tid], kTraceBlock, tl);
+            const bool alive = segment<STATS, MULTI>(p, pt, &s_stack[tid], kTraceBlock, tl);
             if (!alive) {
                 store_color(colors, item, pt.color);
                 tl.paths++;
@@ -1005,8 +1007,13 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
                 else hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), grid, block, lds, stream, q);
                 break;
             case PLAIN:
-                if (stats) hipLaunchKernelGGL(k_trace<true>, grid, block, lds, stream, q);
-                else hipLaunchKernelGGL(k_trace<false>, grid, block, lds, stream, q);
+                if (p.u.bvh_node_count > 1u) {   // per-segment ablation of a multi-node tree
+                    if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, stream, q);
+                    else hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, stream, q);
+                } else {
+                    if (stats) hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, stream, q);
+                    else hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, stream, q);
+                }
                 break;
         }
         e = hipGetLastError();

@@ -35,13 +35,14 @@ def counters(passdir):
 lines = {p: bench_line(f"{out}/{p}.log") for p in "abcd"}
 b = lines["a"]
 kernel = b["roofline"]["kernel"].replace("<false>", "")
-dom = kernel + "<false>"
+def is_dom(name):   # the un-instrumented instantiation of the dominant kernel: k_trace<false, ...>, k_trace_bvh<false, false, 256u>, ...
+    return name.startswith(kernel + "<false")
 steps_run = b["steps"] + b["warmup"]
 seg_run = b["config"]["segments_per_step"] * steps_run     # segments the dominant kernel traced in a PMC pass
 cnt = {}
 for p in "abcd":
     for k, d in counters(f"{out}/{p}").items():
-        if k == dom:
+        if is_dom(k):
             cnt.update({c: v[0] for c, v in d.items()})
             cnt.setdefault("_dispatches", d[next(iter(d))][1])
 acc = {}
@@ -52,7 +53,7 @@ for p in "cd":
 ms = None
 for f in glob.glob(out + "/e/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if dom in r["Name"]:
+        if is_dom(r["Name"].split("(anonymous namespace)::")[-1].split("(")[0]):
             ms = float(r["AverageNs"]) / 1e6
 e = bench_line(f"{out}/e.log")
 fetch_b, write_b = cnt.get("FETCH_SIZE", 0.0) * 1024.0, cnt.get("WRITE_SIZE", 0.0) * 1024.0

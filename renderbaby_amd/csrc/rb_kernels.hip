@@ -523,12 +523,6 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #ifndef RB_FAST_WAVES
 #define RB_FAST_WAVES 4
 #endif
-#ifndef RB_FAST_PHASE2_LANES
-#define RB_FAST_PHASE2_LANES 32   // run the second pass of the triangle walk once this many lanes wait for it
-#endif
-#ifndef RB_FAST_PHASE2_NODE_STEPS
-#define RB_FAST_PHASE2_NODE_STEPS 4
-#endif
 // What trace_stepped needs from a resumable walk: the opt-in triangle walk ...
 template <bool STATS>
 struct TriangleWalkPolicy {
@@ -650,27 +644,22 @@ DEV void trace_stepped(const KParams& p) {
         // node loop 20 % occupied).  At least one pass per outer iteration, then on while enough lanes
         // are still walking.
         if constexpr (Walk::kKinds > 2u) {
-            // Two phases per walk (FastWalk: the library's tree, then the second pass over the reference tree), a node
-            // and a leaf kind of step in each.  Lanes reach the second phase at different times; its steps are cheap
-            // and would run a few lanes at a time if issued whenever someone needs one.  So first-phase steps go first,
-            // by the same rule as for a single-phase walk, and lanes that are done with it wait until
-            // RB_FAST_PHASE2_LANES of them have gathered (or nobody is left in the first phase); then the second
-            // phase runs for all of them, the kind more lanes need, several node steps per vote.
+            // four kinds of step (FastWalk: the library's tree, then the second pass over the reference tree): every
+            // pass runs the kind most lanes are waiting for, node kinds a few steps per vote
             for (;;) {
                 const uint32_t k = state == TRAV ? w.kind() : 4u;
                 const uint32_t n0 = (uint32_t)__popcll(__ballot(k == 0u)), n1 = (uint32_t)__popcll(__ballot(k == 1u)),
                                n2 = (uint32_t)__popcll(__ballot(k == 2u)), n3 = (uint32_t)__popcll(__ballot(k == 3u));
-                if (n0 + n1 + n2 + n3 == 0u) break;
-                uint32_t pick;
-                if (n2 + n3 >= (uint32_t)RB_FAST_PHASE2_LANES || n0 + n1 == 0u) pick = n3 > n2 ? 3u : 2u;
-                else pick = (n1 >= (uint32_t)RB_FAST_LEAF_LANES || n0 < (uint32_t)RB_FAST_NODE_LANES) ? (n1 ? 1u : 0u) : 0u;
+                uint32_t pick = 0u, best = n0;
+                if (n1 > best) { pick = 1u; best = n1; }
+                if (n2 > best) { pick = 2u; best = n2; }
+                if (n3 > best) { pick = 3u; best = n3; }
+                if (best == 0u) break;
                 if (k == pick) {
                     if (!w.step(p, stack, tl)) state = FINISH;
-                    if ((pick & 1u) == 0u) {   // node kinds: a lane reaches a leaf only every few nodes
-                        const int steps = pick == 0u ? Walk::kNodeSteps : RB_FAST_PHASE2_NODE_STEPS;
-                        for (int extra = 1; extra < steps; ++extra)
+                    if ((pick & 1u) == 0u)   // node kinds: a lane reaches a leaf only every few nodes
+                        for (int extra = 1; extra < Walk::kNodeSteps; ++extra)
                             if (state == TRAV && w.kind() == pick && !w.step(p, stack, tl)) state = FINISH;
-                    }
                 }
                 if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
             }

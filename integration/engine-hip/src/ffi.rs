@@ -20,12 +20,26 @@ pub struct RbOptions {
     pub device: i32, pub shard_rank: u32, pub shard_count: u32, pub stripe_rows: u32,
     pub passes_per_launch: u32, pub kernel: u32, pub flags: u32, pub reserved: [u32; 5],
 }
-pub const RB_FLAG_FAST_BVH: u32 = 4;     // opt-in small-leaf tree with culling, same frames
-pub const RB_FLAG_DEVICE_BVH: u32 = 8;   // build that tree on the GPU
+pub const RB_FLAG_FAST_BVH: u32 = 4;             // multi-node meshes: the library's own tree (proved exact, two passes)
+pub const RB_FLAG_DEVICE_BVH: u32 = 8;           // build that tree on the GPU
+pub const RB_FLAG_REFERENCE_WALK: u32 = 32;      // force the reference's walk (the default for multi-node meshes)
+pub const RB_FLAG_HOST_BVH: u32 = 64;            // build that tree on the host
+pub const RB_FLAG_GATHER_PEER_COPY: u32 = 128;   // rb_create_multi without RCCL
+pub const RB_FLAG_NO_RUN_AHEAD: u32 = 256;       // iterator: no pass started ahead of the read-back
+pub const RB_FLAG_SKIP_NEAR_DEGENERATE: u32 = 512; // the library's tree without its second pass (not proved exact)
+pub const RB_COMM_ID_BYTES: usize = 128;
 
 unsafe extern "C" {
     pub fn rb_create(cfg: *const RbConfig) -> *mut RbEngine;
     pub fn rb_create_ex(cfg: *const RbConfig, opt: *const RbOptions) -> *mut RbEngine;
+    /// one handle over several devices of this process: rows sharded in stripes, one RCCL gather per delivered frame
+    pub fn rb_create_multi(cfg: *const RbConfig, opt: *const RbOptions, devices: *const i32, n_devices: u32) -> *mut RbEngine;
+    /// one process per device: rank 0 makes the id, every rank joins with its shard
+    pub fn rb_comm_unique_id(id_out: *mut u8) -> c_int;
+    pub fn rb_comm_init_rank(e: *mut RbEngine, id: *const u8, rank: u32, nranks: u32) -> c_int;
+    /// page-locked frame memory: read-backs into it are DMA copies that overlap the next pass
+    pub fn rb_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn rb_host_free(p: *mut c_void);
     pub fn rb_destroy(e: *mut RbEngine);
     pub fn rb_update(e: *mut RbEngine, cfg: *const RbConfig) -> c_int;
     pub fn rb_render(e: *mut RbEngine, rgba_out: *mut u8) -> c_int;

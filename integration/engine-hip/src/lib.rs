@@ -58,10 +58,39 @@ fn frame_for(e: *mut ffi::RbEngine) -> Result<Frame> {
     Ok(Frame::new(w as usize, h as usize, vec![0u8; w as usize * h as usize * 4]))
 }
 
+/// What has no counterpart in the reference (one wgpu device, one pass per frame, its own walk): which devices,
+/// which walk for multi-node meshes, how often the iterator delivers.  `Default` = one device, the reference's
+/// behaviour throughout.
+#[derive(Default, Clone)]
+pub struct EngineOptions {
+    pub devices: Vec<i32>,            // empty: the current device; several: one handle over all of them
+    pub stripe_rows: u32,             // rows per stripe of the row sharding (0 = 16)
+    pub own_tree: bool,               // RB_FLAG_FAST_BVH: the library's tree for multi-node meshes (same frames)
+    pub device_built_tree: bool,      // RB_FLAG_DEVICE_BVH
+    pub passes_per_frame: u32,        // iterator: a frame every n samples (0 / 1 = every sample)
+}
+
 impl Engine {
     pub fn new(rc: RenderConfig) -> Self {                       // engine-pathtracer lib.rs:111-119
-        let e = with_config(&rc, |c| unsafe { ffi::rb_create(c) });
+        Self::with_options(rc, &EngineOptions::default())
+    }
+    pub fn with_options(rc: RenderConfig, o: &EngineOptions) -> Self {
+        let opt = ffi::RbOptions {
+            device: -1, stripe_rows: o.stripe_rows,
+            flags: if o.own_tree { ffi::RB_FLAG_FAST_BVH } else { 0 } | if o.device_built_tree { ffi::RB_FLAG_DEVICE_BVH } else { 0 },
+            ..Default::default()
+        };
+        let e = with_config(&rc, |c| unsafe {
+            if o.devices.len() > 1 {
+                // rows in interleaved stripes over the devices, ONE RCCL gather per delivered frame inside the library
+                ffi::rb_create_multi(c, &opt, o.devices.as_ptr(), o.devices.len() as u32)
+            } else {
+                let opt = ffi::RbOptions { device: o.devices.first().copied().unwrap_or(-1), ..opt };
+                ffi::rb_create_ex(c, &opt)
+            }
+        });
         assert!(!e.is_null(), "{}", unsafe { CStr::from_ptr(ffi::rb_last_error(ptr::null())) }.to_string_lossy());
+        if o.passes_per_frame > 1 { unsafe { ffi::rb_iter_set_passes_per_frame(e, o.passes_per_frame); } }
         Self { h: Arc::new(Mutex::new(Handle(e))) }
     }
 }

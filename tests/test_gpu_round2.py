@@ -241,3 +241,52 @@ def test_pinned_frame_buffers_receive_the_same_frames():
     assert np.array_equal(pf.array, want[-1])
     e.close()
     pf.free()
+
+
+def test_destroy_with_a_pass_still_running_ahead():
+    # rb_destroy must wait for whatever the engine's streams still hold -- here the pass the iterator started
+    # ahead of the caller -- before events, streams and buffers go (r01 recorded a host segmentation fault after
+    # ~50 000 create / destroy cycles that was never explained; this is the one ordering the churn did not cover)
+    s = scenes.cornell(96, 64, 8, 6)
+    rc = RenderConfig.from_scene(s)
+    want = _oracle.render(s, 0, 2)[2]
+    for i in range(150):
+        e = Engine.new(rc)
+        it = e.frame_iterator(rc)
+        it.next()
+        f = it.next()       # the third pass is in flight on the second slot now
+        if i % 50 == 0:
+            assert np.array_equal(f.pixels, want)
+        e.close()
+
+
+def test_getters_from_another_thread_while_rendering():
+    # rb_get_size / rb_last_error used to read engine state without the engine's lock (rb_get_size even wrote the
+    # error string of a const engine): a GUI thread polling them next to the render thread raced on a std::string
+    import threading
+    s = scenes.cornell(64, 48, 3, 4)
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc)
+    e.update(rc)
+    stop = threading.Event()
+    seen = []
+
+    def poll():
+        while not stop.is_set():
+            seen.append(e.size())
+            e._lib.rb_last_error(e._h)
+            e._lib.rb_iter_has_next(e._h)
+
+    t = threading.Thread(target=poll)
+    t.start()
+    try:
+        bad = RenderConfig(uniforms=Change.update(s.uniforms), uvs=Change.update(np.zeros(3, np.float32)))
+        for _ in range(60):
+            f = e.render(RenderConfig.from_scene(s, create=False))
+            with pytest.raises(RenderError):
+                e.update(bad)      # keeps rewriting the error string under the poller
+    finally:
+        stop.set()
+        t.join()
+    assert np.array_equal(f.pixels, _oracle.render(s)[2]) and set(seen) == {(64, 48)}
+    e.close()

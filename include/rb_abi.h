@@ -334,7 +334,7 @@ void rb_iter_destroy(rb_engine* e);
 int rb_iter_set_passes_per_frame(rb_engine* e, uint32_t n);
 
 /* anyhow error text of the last failing call on `e` (or of rb_create when
- * e == NULL).  Valid until the next call on the same engine/thread. */
+ * e == NULL): a copy owned by the calling thread, valid until that thread's next rb_last_error. */
 const char* rb_last_error(const rb_engine* e);
 
 /* GpuWrapper::get_width/get_height -- gpu_wrapper.rs:317-329 */

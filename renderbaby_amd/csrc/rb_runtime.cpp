@@ -140,6 +140,7 @@ struct rb_engine {
     float sph_bmin[3] = {0, 0, 0}, sph_bmax[3] = {0, 0, 0};
     bool sph_bvh = false;
     DevBuf<float> colors;            // RB_KERNEL_STREAM: float4 per (pixel, sample) of one launch chunk
+    uint64_t color_budget = 0;       // bytes `colors` may take (0 = ask the device at the next dispatch)
     uint32_t bvh_stack = 0;          // traversal-stack entries the current tree needs
 
     std::vector<rb_bvh_node> host_nodes;  // kept for validation when nodes/indices change separately
@@ -731,12 +732,15 @@ int accumulate_timing(rb_engine* e) {
 // Colour-buffer budget of the stream kernels (one float4 per (pixel, sample) of a launch chunk): the caller's
 // figure, else 4 GiB but never more than half of what the device has free right now -- eight launches per C2
 // frame instead of one cost 0.4 %, and a library that sits behind a GUI should not take 34 GB for a 1080p frame.
-uint64_t color_budget_bytes(const rb_engine* e) {
+uint64_t color_budget_bytes(rb_engine* e) {
     if (e->opt._reserved[1]) return static_cast<uint64_t>(e->opt._reserved[1]) << 20;
-    uint64_t budget = 4ull << 30;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, (free_b + e->colors.count * sizeof(float)) / 2);
-    return std::max<uint64_t>(budget, 1ull << 20);
+    if (e->color_budget == 0) {   // asked once per update: hipMemGetInfo is a driver round trip, and the iterator dispatches per pass
+        uint64_t budget = 4ull << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, (free_b + e->colors.count * sizeof(float)) / 2);
+        e->color_budget = std::max<uint64_t>(budget, 1ull << 20);
+    }
+    return e->color_budget;
 }
 
 // dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400: passes
@@ -856,6 +860,7 @@ int update_fields(rb_engine* e, const rb_config* cfg) {
     // ---- from here on the buffers change; a device failure half-way leaves the engine refusing to render
     e->scene_valid = false;
     e->spec_valid = false;
+    e->color_budget = 0;
     // uniforms (gpu_wrapper.rs:122-136 / :165-192)
     const bool take_uniforms = first ? (cfg->uniforms.change == RB_CREATE) : (cfg->uniforms.change == RB_UPDATE);
     if (take_uniforms) {
@@ -1217,10 +1222,14 @@ void rb_destroy(rb_engine* e) {
 
 const char* rb_last_error(const rb_engine* e) {
     if (!e) return g_create_error.c_str();
-    // the text stays valid until the next failing call on this engine (rb_abi.h); the lock only orders
-    // this read against a concurrent writer's assignment
-    std::lock_guard<std::mutex> g(e->err_mu);
-    return e->error.c_str();
+    // a copy per calling thread: another thread's failing call may replace the engine's text at any moment
+    // (the reference's GUI polls from its own thread), and a pointer into that string would dangle
+    thread_local std::string mine;
+    {
+        std::lock_guard<std::mutex> g(e->err_mu);
+        mine = e->error;
+    }
+    return mine.c_str();
 }
 
 int rb_update(rb_engine* e, const rb_config* cfg) {

@@ -379,9 +379,13 @@ Act field_action(int idx, const rb_field& f, bool first) {
     return Act::None;
 }
 
-bool wants_own_tree(const rb_engine* e) {
+// may the library's own tree be wanted for this engine's meshes?  (host copies of triangles / indices are kept then)
+bool may_want_own_tree(const rb_engine* e) { return !(e->opt.flags & RB_FLAG_REFERENCE_WALK); }
+// is it wanted for a mesh of n_tris triangles?
+bool wants_own_tree(const rb_engine* e, uint32_t n_tris) {
     if (e->opt.flags & RB_FLAG_REFERENCE_WALK) return false;
-    return rb::kFastWalkByDefault || (e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) != 0u;
+    if (e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) return true;
+    return n_tris >= rb::kOwnTreeDefaultMinTriangles;
 }
 
 int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
@@ -419,13 +423,13 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
         case 6:
             rc = upload(e, e->indices, src, n, &e->n_indices, true);
             e->prep_dirty = true;
-            if (wants_own_tree(e)) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
+            if (may_want_own_tree(e)) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
             break;
         case 7:
             rc = upload(e, e->tris, src, n, nullptr, true);
             e->n_tris = static_cast<uint32_t>(n);
             e->prep_dirty = true;
-            if (wants_own_tree(e)) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
+            if (may_want_own_tree(e)) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
             break;
         case 8:
             if (del) { rb_field empty{RB_UPDATE, nullptr, 0}; rc = upload_textures(e, empty); }
@@ -536,7 +540,7 @@ int ensure_prepared(rb_engine* e) {
     e->prep_tri_count = tri_count;
     // ---- the library's own tree over the same triangles (default for multi-node meshes)
     e->fast_ready = false;
-    if (wants_own_tree(e) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+    if (wants_own_tree(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
         rb::FastTree ft;
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size());

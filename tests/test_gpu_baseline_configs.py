@@ -88,8 +88,8 @@ def test_c5_million_triangle_mesh_matches_the_oracle():
         out[mode] = (e.read_accumulation(), f.pixels, e.stats()["segments"], e.last_kernel_name())
         if mode in ("host-sah", "device-ploc"):
             assert e.fast_bvh_builder()[0] == mode
-        if mode == "default":   # the library's default for multi-node meshes is the reference walk
-            assert e.fast_bvh_builder()[0] == "" and e.last_kernel_name() == "k_trace_bvh"
+        if mode == "default":   # a mesh whose triangles outgrow L2: the library's own tree, built on the device
+            assert e.fast_bvh_builder()[0] == "device-ploc" and e.last_kernel_name() == "k_trace_fast"
         e.close()
     assert out["reference-walk"][3] == "k_trace_bvh" and out["host-sah"][3] == "k_trace_fast"
     r0, r1 = rows

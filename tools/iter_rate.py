@@ -10,7 +10,7 @@ for (w, h) in ((512, 512), (1920, 1080)):
     rc = RenderConfig.from_scene(s)
     for kern in (abi.KERNEL_STREAM, abi.KERNEL_QUEUE):
         for ahead, pinned in ((True, True), (True, False), (False, False)):
-            e = Engine.new(rc, kernel=kern, no_run_ahead=not ahead)
+            e = Engine.new(rc, kernel=kern, no_run_ahead=not ahead, blocks_per_cu=int(os.environ.get('RB_BPC', '0')))
             cfg, keep = rc.to_c()
             e._check(e._lib.rb_iter_begin(e._h, __import__("ctypes").byref(cfg)))
             del keep

@@ -900,19 +900,24 @@ int device_cu_count(int device) {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
-static uint32_t persistent_blocks(uint64_t items, uint32_t block, uint32_t blocks_per_cu) {
+static uint32_t device_cu_count_cached() {   // of the current device; asked once per device
+    static int cached[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    uint32_t blocks = (uint32_t)device_cu_count(dev) * blocks_per_cu;
+    if (dev < 0 || dev >= 64) return (uint32_t)device_cu_count(dev);
+    if (cached[dev] == 0) cached[dev] = device_cu_count(dev);
+    return (uint32_t)cached[dev];
+}
+
+static uint32_t persistent_blocks(uint64_t items, uint32_t block, uint32_t blocks_per_cu) {
+    uint32_t blocks = device_cu_count_cached() * blocks_per_cu;
     const uint64_t needed = (items + block - 1) / block;
     if (needed < blocks) blocks = (uint32_t)needed;
     return blocks;
 }
 
 uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return (uint32_t)device_cu_count(dev) * (blocks_per_cu ? blocks_per_cu : 8u) * 256u;  // k_trace / k_queue blocks are <= 256 threads
+    return device_cu_count_cached() * (blocks_per_cu ? blocks_per_cu : 8u) * 256u;  // k_trace / k_queue blocks are <= 256 threads
 }
 
 int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info, void* ev_after_trace) {
@@ -964,7 +969,11 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         li.block = v == BVH_LDS ? 1024u : kTraceBlock;
         li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : lds;
         // residency (registers): k_trace 6 waves/SIMD, the stepped walks 4
-        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : 8u;
+        // (a launch of one or two samples per pixel -- the progressive iterator's -- leaves a wavefront of the full grid a
+        // few hundred items: with half the grid each regenerates paths for longer and the tail is shorter: 1080p, 1 spp,
+        // 0.72 instead of 0.80 ms per frame)
+        const uint32_t dense = (items >= (uint64_t)device_cu_count_cached() * 8u * 4u * 1024u) ? 8u : 4u;
+        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : dense;
         li.grid = persistent_blocks(items, li.block, blocks_per_cu);
         if (li.grid == 0) return 0;
         // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64

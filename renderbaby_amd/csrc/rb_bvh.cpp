@@ -482,6 +482,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
     out.slot_meta.assign(static_cast<size_t>(index_len) * 2, 0xFFFFFFFFu);
     std::vector<uint32_t> st{0u};
     std::vector<uint32_t> slots, order;   // order: reachable nodes, parents before children
+    std::vector<TriBound> bound(index_len);   // per slot (valid slots only), made once: the cones below use it again
     uint32_t rank = 0;
     while (!st.empty()) {
         const uint32_t ni = st.back();
@@ -494,7 +495,8 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 if (slot >= index_len) continue;                     // guard :331
                 if (indices[slot] >= tri_count) { ++rank; continue; }  // guard :336
                 if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the reference walk
-                const bool large = tri_bound(tris[indices[slot]]).large;
+                bound[slot] = tri_bound(tris[indices[slot]]);
+                const bool large = bound[slot].large;
                 out.slot_meta[slot * 2] = ni;
                 out.slot_meta[slot * 2 + 1] = rank++ | (large ? kSlotLarge : 0u);
                 out.n_large += large ? 1u : 0u;
@@ -524,7 +526,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 const uint32_t slot = n.first_primitive + i;
                 if (slot >= index_len || indices[slot] >= tri_count) continue;
                 const rb_gpu_triangle& t = tris[indices[slot]];
-                const TriBound b = tri_bound(t);
+                const TriBound& b = bound[slot];
                 if (!b.large) continue;
                 out.gslots.push_back(slot);
                 double l1 = 0, l2 = 0;

@@ -10,7 +10,7 @@ print(w, "triangles", len(s.bvh_triangles), "scene generation %.2f s" % (time.ti
 t = time.time(); n, i = bvh.build(s.bvh_triangles); print("reference-style build (host, rb_bvh_build) %.3f s, %d nodes" % (time.time() - t, len(n)))
 rc = RenderConfig.from_scene(s)
 for fast, dev in ((False, False), (True, False), (True, True)):
-    t = time.time(); eng = Engine.new(rc, fast_bvh=fast, device_bvh=dev); t1 = time.time() - t
+    t = time.time(); eng = Engine.new(rc, reference_walk=not (fast or dev), host_bvh=fast and not dev, device_bvh=dev); t1 = time.time() - t
     t = time.time(); eng.update(rc); eng.sync(); t2 = time.time() - t
     t = time.time(); eng.clear(); eng.dispatch(0, 4); eng.sync(); t3 = time.time() - t
     t = time.time(); eng.clear(); eng.dispatch(0, 4); eng.sync(); t4 = time.time() - t

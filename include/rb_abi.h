@@ -230,8 +230,11 @@ enum {
 enum {
     RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
-    RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first)
-                              and accept a hit only if the reference's traversal would have tested it; same frames */
+    RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first) plus
+                              a second pass over the caller's tree for hits reported from near-zero determinants, and accept
+                              a hit only if the reference's traversal would have tested it: proved to deliver the reference
+                              walk's frames.  Without this flag or RB_FLAG_REFERENCE_WALK the library
+                              chooses: its own tree from 393 216 triangles up, the reference walk below */
     RB_FLAG_DEVICE_BVH = 8u, /* with RB_FLAG_FAST_BVH: build that tree on the GPU (Morton order + locally-ordered
                                 clustering) instead of on the host (binned SAH): milliseconds instead of ~0.5 s per
                                 million triangles, the same frames */
@@ -415,7 +418,7 @@ int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uin
  * "k_queue", "k_pixel"). */
 const char* rb_last_kernel_name(const rb_engine* e);
 
-/* Which builder produced the tree RB_FLAG_FAST_BVH walks: "host-sah", "device-lbvh", or "" when
+/* Which builder produced the library's own tree: "host-sah", "device-ploc", "device-lbvh", or "" when
  * there is none (flag not set, single-node tree, or the scene keeps the exact walk).  Valid after the
  * first rb_dispatch / rb_render that follows an update.  `build_ms`, if not NULL, receives the wall
  * time of that build including its uploads. */

@@ -9,6 +9,25 @@ namespace rb {
 namespace {
 
 // ------------------------------------------------------------- materials --
+// The launch parameters, fetched again from the kernel-argument segment (every render kernel takes one KParams by
+// value, so it sits at offset 0).  A kernel that keeps every field it will ever need in scalar registers across its
+// whole loop runs out of them (102 per wave): the allocator spills to lanes of a vector register and every use
+// costs a v_readlane, a vector-unit slot.  Starting a phase of the loop from a pointer the compiler cannot see
+// through makes that phase load what it needs with scalar loads (the scalar cache holds them) and ends the live
+// ranges at the phase's end.  k_trace on C2: 411 -> 78 v_readlane in the loop body, + 5.6 % (profiles/r02_fresh_params.txt).
+#ifndef RB_FRESH_PARAMS
+#define RB_FRESH_PARAMS 1
+#endif
+DEV const KParams& fresh_params(const KParams& p) {
+#if RB_FRESH_PARAMS
+    const RB_CONST char* k = (const RB_CONST char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const KParams*)k;
+#else
+    return p;
+#endif
+}
+
 struct Mat {
     f3 diffuse, specular, emissive;
     float fuzz;     // clamp(1 - shininess / 1000, 0, 1)   (shader.wgsl:637)
@@ -449,17 +468,17 @@ DEV bool segment_post(const KParams& p, Path& pt, const TriHit th, const SegStat
 template <bool STATS>
 DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
                         Tally<STATS>& tl) {
-    const SegState st = segment_pre<STATS>(p, pt, th, tl);
+    const SegState st = segment_pre<STATS>(fresh_params(p), pt, th, tl);
     float closest_t = st.closest_t;
     uint32_t sphere_idx = 0xFFFFFFFFu;
-    segment_spheres<STATS>(p, pt.o, pt.d, dot(pt.d, pt.d), closest_t, sphere_idx, stack, stride, tl);
-    return segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
+    segment_spheres<STATS>(fresh_params(p), pt.o, pt.d, dot(pt.d, pt.d), closest_t, sphere_idx, stack, stride, tl);
+    return segment_post<STATS>(fresh_params(p), pt, th, st, closest_t, sphere_idx, tl);
 }
 
 // One whole iteration of the bounce loop: traversal + everything else.
 template <bool STATS, bool MULTI = true>
 DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
-    const TriHit th = intersect_bvh<STATS, MULTI>(p, pt.o, pt.d, stack, stride, tl);
+    const TriHit th = intersect_bvh<STATS, MULTI>(fresh_params(p), pt.o, pt.d, stack, stride, tl);
 #if RB_ABLATE == 1
     {
         f3 o2 = pt.o;
@@ -473,43 +492,37 @@ DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, T
 }
 
 // ----------------------------------------------------------------- camera --
-struct Cam {
-    f3 pos, right, up, fwd;
-    float fov, aspect, wm1, hm1;
-};
-// shader.wgsl:690,702-708 (per-launch invariants of the sample loop)
-DEV Cam make_cam(const KParams& p) {
-    Cam c;
-    c.aspect = (float)p.u.width / (float)p.u.height;
-    c.pos = ld3(p.u.camera.pos);
-    c.fwd = normalize(ld3(p.u.camera.dir));
-    c.right = normalize(cross(mk(0.0f, 1.0f, 0.0f), c.fwd));
-    c.up = cross(c.fwd, c.right);
-    c.fov = p.u.camera.pane_width / (2.0f * p.u.camera.pane_distance * c.aspect);
-    c.wm1 = (float)(p.u.width - 1u);
-    c.hm1 = (float)(p.u.height - 1u);
-    return c;
-}
 // shader.wgsl:693-709; `sample_hash` = hash(current_pass * samples_per_pass + sample), the part of the seed
 // that does not depend on the pixel
-DEV void start_path_hashed(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
-                           uint32_t sample_hash, Path& pt) {
+// (p.cam: rb_internal.hpp; callers pass fresh_params(p) so that the camera is not held in registers between path starts)
+DEV void start_path_hashed(const KParams& p, uint32_t x, uint32_t y, uint32_t pixel_index, uint32_t sample_hash, Path& pt) {
+    const Cam& c = p.cam;
     uint32_t seed = pcg(pixel_index + sample_hash);
     const float off_x = rnd(seed) - 0.5f;
     const float off_y = rnd(seed) - 0.5f;
-    const float u = ((((float)x + off_x) / c.wm1) * 2.0f - 1.0f) * c.aspect;
-    const float v = 1.0f - (((float)y + off_y) / c.hm1) * 2.0f;
-    pt.o = c.pos;
-    pt.d = normalize(((c.fov * u) * c.right + (c.fov * v) * c.up) + c.fwd);
+    // the two divisions by launch constants: the exact quotient from the exact reciprocal (div_newton; the numerators
+    // are zero or at least 2^-33 in magnitude, multiples of the sampler's 2^-32 grid), the compiler's expansion otherwise
+    const float ax = (float)x + off_x, ay = (float)y + off_y;
+    float qx, qy;
+    if (c.fast_wh) {
+        qx = __builtin_copysignf(div_newton(ax, c.wm1, c.inv_wm1), ax);
+        qy = __builtin_copysignf(div_newton(ay, c.hm1, c.inv_hm1), ay);
+    } else {
+        qx = ax / c.wm1;
+        qy = ay / c.hm1;
+    }
+    const float u = ((qx * 2.0f) - 1.0f) * c.aspect;
+    const float v = 1.0f - qy * 2.0f;
+    pt.o = ld3(c.pos);
+    pt.d = normalize(((c.fov * u) * ld3(c.right) + (c.fov * v) * ld3(c.up)) + ld3(c.fwd));
     pt.seed = seed;
     pt.color = mk(0, 0, 0);
     pt.att = mk(1, 1, 1);
     pt.depth = 0;
 }
 
-DEV void start_path(const KParams& p, const Cam& c, uint32_t x, uint32_t y, uint32_t pixel_index,
-                    uint32_t sample_offset, Path& pt) {
-    start_path_hashed(p, c, x, y, pixel_index, pcg(sample_offset), pt);
+DEV void start_path(const KParams& p, uint32_t x, uint32_t y, uint32_t pixel_index, uint32_t sample_offset, Path& pt) {
+    start_path_hashed(p, x, y, pixel_index, pcg(sample_offset), pt);
 }
 
 // global image row of local row `ly` (interleaved stripes)

@@ -53,8 +53,15 @@ constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the librar
 constexpr float kFastGrazeCos = 0.03f;
 // A triangle whose determinant bound L^2 / 1e-6 (the reference rejects |a^| < 1e-6) is at most this is "small": the
 // culling margin of the library's tree then covers ALL its accepted hits, near-degenerate ones included, and the
-// second pass skips it.  1500 <=> L <= 0.039: a margin of at most 2.4e-3 of the distance to the box.
-constexpr float kFastSmallCap = 1500.0f;
+// second pass skips it.  16000 <=> L <= 0.126: a margin of at most 2.6e-2 of the distance to the box.  A tuning
+// constant, not part of the proof (any value up to 1.5e5 is covered): larger = fewer triangles left to the second
+// pass but wider margins in the first.  Measured (profiles/r02_small_cap_sweep.txt, M segments/s at 1500 / 8000 /
+// 16000 / 32000 / 64000 / 150000): C5 744 / 1603 / 1600 / 1608 / 1604 / 1601, reference lamp scene 669 / 750 / 1066 /
+// 1065 / 1102 / 909, C3 448 / 450 / 460 / 244 / 181 / 216.
+#ifndef RB_FAST_SMALL_CAP
+#define RB_FAST_SMALL_CAP 16000.0f
+#endif
+constexpr float kFastSmallCap = RB_FAST_SMALL_CAP;
 constexpr uint32_t kSlotLarge = 0x80000000u;   // slot_meta[2 * slot + 1]: bit 31 = "large" triangle, low bits = reference rank
 // A node of the reference tree as that second pass reads it: the caller's box and links bit for bit (the pass
 // repeats the reference's own slab test), plus the cone {axis cos(alpha), tan(alpha)} of the triangle normals below.
@@ -135,6 +142,17 @@ struct alignas(16) PrepTriShade {   // 16 B: uv lookup indices (shader.wgsl:357-
     uint32_t _pad;
 };
 
+// The per-launch invariants of the sample loop (shader.wgsl:690,702-708), worked out once on the host by
+// launch_render (host_cam in rb_kernels.hip: the same single IEEE binary32 operations, in the shader's order) so
+// that no kernel holds twenty registers for them: a path start reads them from the kernel arguments.
+struct Cam {
+    float pos[3], right[3], up[3], fwd[3];
+    float fov, aspect, wm1, hm1;
+    float inv_wm1, inv_hm1;  // RN(1 / wm1), RN(1 / hm1) when fast_wh
+    uint32_t fast_wh;        // both denominators inside the ranges the exact-reciprocal division was checked for
+    uint32_t _pad;
+};
+
 // Everything a render launch needs.  Passed by value (kernarg segment => scalar loads).
 struct KParams {
     rb_uniforms u;  // counts already patched (gpu_wrapper.rs:475-495) and clamped to buffer lengths
@@ -191,6 +209,7 @@ struct KParams {
     uint32_t lds_mode;             // LDS staging of small meshes: 0 = when it fits, 1 = never
     uint32_t magic_S, magic_tiles_x; // floor(2^32 / d) for the item decode of the stream kernels (set by launch_render)
     uint32_t* stack_overflow;      // fast walk: entries beyond kStackDepth, [entry][grid * block] (nullptr if never needed)
+    Cam cam;                       // set by launch_render
 };
 
 struct LaunchInfo {

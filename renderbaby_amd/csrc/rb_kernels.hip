@@ -43,7 +43,6 @@ __global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
         active = y < p.u.height;
     }
     if (active) {
-        const Cam cam = make_cam(p);
         const uint32_t pixel_index = y * p.u.width + x;
         const float4 a4 = reinterpret_cast<const float4*>(p.accum_in)[(size_t)ly * p.u.width + x];
         f3 acc = mk(a4.x, a4.y, a4.z);
@@ -51,7 +50,7 @@ __global__ void __launch_bounds__(kPixelBlock) k_pixel(const KParams p) {
         for (uint32_t pass = p.first_pass; pass < p.first_pass + p.n_passes; pass++) {
             for (uint32_t s = 0; s < p.samples_per_pass; s++) {
                 Path pt;
-                start_path(p, cam, x, y, pixel_index, pass * p.samples_per_pass + s, pt);
+                start_path(fresh_params(p), x, y, pixel_index, pass * p.samples_per_pass + s, pt);
                 if (p.u.max_depth > 0u) {
                     while (segment<STATS>(p, pt, &s_stack[tid], kPixelBlock, tl)) {
                     }
@@ -87,7 +86,6 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
     const uint32_t total_items = tiles_x * tiles_y * 64u;  // host guarantees < 2^32
     const uint32_t samples_total = p.n_passes * p.samples_per_pass;
     const uint32_t sample_base = p.first_pass * p.samples_per_pass;
-    const Cam cam = make_cam(p);
     Tally<STATS> tl;
 
     bool have_pixel = false;   // lane owns a pixel
@@ -139,7 +137,7 @@ __global__ void __launch_bounds__(kQueueBlock) k_queue(const KParams p) {
         }
         if (have_pixel) {
             if (!in_path) {
-                start_path(p, cam, x, y, pixel_index, sample_base + sample, pt);
+                start_path(fresh_params(p), x, y, pixel_index, sample_base + sample, pt);
                 in_path = p.u.max_depth > 0u;
             }
             if (in_path) in_path = segment<STATS>(p, pt, &s_stack[tid], kQueueBlock, tl);
@@ -177,20 +175,82 @@ constexpr uint32_t kTraceBlock = 256;
 // Lanes finish at different times, so these are lone 16-byte stores: HBM takes them as 32-byte
 // writes (measured 2.2x the payload).  Streaming stores at least avoid the line fills and the early
 // partial write-backs of cached ones (2.45x plus 0.2x fetched); the kernel time is the same either way.
+// k_trace, whose frames are the large ones, does not store this way: see ColorRing.
 #ifndef RB_COLOR_STORE_NT
 #define RB_COLOR_STORE_NT 1
 #endif
-DEV void store_color(float4* __restrict__ colors, uint32_t item, f3 c) {
+DEV void store_color4(float4* __restrict__ colors, uint32_t item, v4f v) {
 #if RB_COLOR_STORE_NT
-    const v4f v = {c.x, c.y, c.z, 0.0f};
     __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(colors) + item);
 #else
-    colors[item] = make_float4(c.x, c.y, c.z, 0.0f);
+    reinterpret_cast<v4f*>(colors)[item] = v;
 #endif
 }
+DEV void store_color(float4* __restrict__ colors, uint32_t item, f3 c) {
+    const v4f v = {c.x, c.y, c.z, 0.0f};
+    store_color4(colors, item, v);
+}
+
+// Write combining for the colour buffer of k_trace: one ring of kRingRows x 64 entries per wavefront in LDS.
+// A wave is handed items in ascending order from reservations that are multiples of 64, so it works through
+// 64-item rows of the buffer (one sample of one 8 x 8 tile: 1 KiB); row r uses ring slice r mod kRingRows, entry
+// item mod 64.  A finished path parks its radiance there, tagged item + 1 (one ds_write_b128).  Before the first
+// item of a new row is handed out, the whole wave empties the slice that row will use: lane l stores entry l, so
+// the two (usually all eight) finished neighbours of a 32-byte sector (128-byte line) leave in one instruction
+// and the memory side sees whole sectors instead of lone 16-byte stores that it rounds up to 32 bytes each.
+// Reservations are multiples of kRingRows rows (launch_render), so the slices come round in order whatever the
+// jumps between reservations: that slice holds the row handed out kRingRows rows -- about 20 loop iterations -- earlier, and a path takes at
+// most max_depth iterations, so at the default depths nearly every entry is there.  A lane still tracing an item of that
+// slice is marked (kDirect in its item word) and stores on its own when it finishes, as every lane used to.
+// Nothing is ever parked in an occupied entry: the slice was emptied before its row's first item went out, and
+// the stragglers of the previous row were marked in the same step.
+#ifndef RB_COLOR_COMBINE
+#define RB_COLOR_COMBINE 1
+#endif
+constexpr uint32_t kRingRows = 4u, kDirect = 0x80000000u;
+// LDS-qualified pointers: with generic ones the compiler folds "park or store directly" into one FLAT store through a
+// selected address, which is slower than either and loses the streaming hint
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct ColorRing {
+    lds_v4f* ring;  // this wave's kRingRows * 64 entries
+
+    DEV ColorRing(v4f* block_rings, uint32_t wave, uint32_t lane)
+        : ring((lds_v4f*)(block_rings + wave * (kRingRows * 64u))) {
+        for (uint32_t k = 0; k < kRingRows; k++) tag(k * 64u + lane) = 0u;
+    }
+    DEV lds_u32& tag(uint32_t e) const { return ((lds_u32*)ring)[e * 4u + 3u]; }
+
+    // a finished path; `item` may carry kDirect
+    DEV void finish(float4* __restrict__ colors, uint32_t item, f3 c) const {
+        if (item & kDirect) {
+            store_color(colors, item & ~kDirect, c);
+        } else {
+            const v4f v = {c.x, c.y, c.z, __uint_as_float(item + 1u)};
+            ring[item & (kRingRows * 64u - 1u)] = v;
+        }
+    }
+    // all 64 lanes, before the first item of row `row` is handed out
+    DEV void open_row(float4* __restrict__ colors, uint32_t lane, uint32_t row, bool active, uint32_t& item) const {
+        const uint32_t slice = row & (kRingRows - 1u);
+        drain(colors, lane, slice);
+        if (active && ((item >> 6) & (kRingRows - 1u)) == slice) item |= kDirect;
+    }
+    DEV void drain(float4* __restrict__ colors, uint32_t lane, uint32_t slice) const {
+        const uint32_t e = slice * 64u + lane;
+        v4f v = ring[e];
+        const uint32_t t = __float_as_uint(v.w);
+        if (t != 0u) {
+            v.w = 0.0f;
+            store_color4(colors, t - 1u, v);
+            tag(e) = 0u;
+        }
+    }
+};
 #ifndef RB_TRACE_WAVES
 #define RB_TRACE_WAVES 6
 #endif
+constexpr uint64_t kTraceManyItems = 1ull << 26;  // launches from here on take k_trace's 8-wave instantiation
 
 // The (pixel, sample) work queue of the stream kernels, one instance per wavefront.  The global
 // queue word is touched once per `batch` items (one word sustains only ~90 M atomics/s chip-wide);
@@ -241,8 +301,11 @@ struct ItemQueue {
 
 // MULTI = false: trees of at most one node only (the default instantiation: launch_render sends every multi-node
 // tree to a stepped kernel); MULTI = true: the per-segment ablation of those (opt no_leaf_stepping).
-template <bool STATS, bool MULTI>
-__global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KParams p) {
+// WAVES = resident waves per SIMD the register allocation aims for: 6 (80 registers, nothing spilled) except for the
+// large launches of the default instantiation, which run 0.5 % faster with 8 (64 registers, 9 spilled outside the
+// segment code) -- and 2-3 % slower on one-sample frames, hence two instantiations.
+template <bool STATS, bool MULTI, int WAVES = RB_TRACE_WAVES>
+__global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -251,10 +314,16 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
     const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
     const uint32_t S = p.n_passes * p.samples_per_pass;
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;  // host keeps this < 2^31
-    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
-    const Cam cam = make_cam(p);
+    [[maybe_unused]] const uint32_t sample_base = p.first_pass * p.samples_per_pass;
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
     Tally<STATS> tl;
+#if RB_COLOR_COMBINE
+    __shared__ __attribute__((aligned(16))) v4f s_ring[(kTraceBlock / 64u) * kRingRows * 64u];
+    ColorRing cring(s_ring, tid >> 6, lane);
+    // rows follow each other through the ring's slices only if every reservation starts on a multiple of
+    // kRingRows rows; the launcher arranges that for frames large enough, the others store directly
+    const uint32_t direct_mask = (p.queue_batch % (kRingRows * 64u)) ? kDirect : 0u;
+#endif
 
     bool active = false, exhausted = false;
     uint32_t item = 0;
@@ -280,27 +349,48 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
-            const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
+#if RB_FRESH_PARAMS
+            // the launch constants this round needs, fetched again from the kernel arguments (scalar loads): held in
+            // scalar registers across the segment code they would be spilled and come back through v_readlane, one
+            // vector-unit slot each
+            const KParams& rp = fresh_params(p);
+            const uint32_t rS = rp.n_passes * rp.samples_per_pass, r_tiles_x = (rp.u.width + 7u) / 8u;
+            const uint32_t r_sample_base = rp.first_pass * rp.samples_per_pass, r_width = rp.u.width;
+#else
+            const KParams& rp = p;
+            const uint32_t rS = S, r_tiles_x = tiles_x, r_sample_base = sample_base, r_width = width;
+#endif
+            const ItemRows rows = item_rows(rp, loc_next, rS, r_tiles_x, r_sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = !active && rank < avail;
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const uint32_t taken = n_idle < avail ? n_idle : avail;
+#if RB_COLOR_COMBINE
+            if (direct_mask == 0u) {
+                if (rows.in0 == 0u) cring.open_row(colors, lane, loc_next >> 6, active, item);
+                else if (rows.in0 + taken > 64u) cring.open_row(colors, lane, (loc_next >> 6) + 1u, active, item);
+            }
+#endif
             if (take) {
                 const uint32_t it = loc_next + rank;
                 uint32_t x = 0, y = 0, sample_hash = 0;
-                if (item_pixel(p, rows, rank, x, y, sample_hash)) {
-                    start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                if (item_pixel(rp, rows, rank, x, y, sample_hash)) {
+                    start_path_hashed(rp, x, y, y * r_width + x, sample_hash, pt);
 #if RB_ABLATE == 4
                     {
                         Path p2;
                         uint32_t x2 = x;
                         asm volatile("" : "+v"(x2));
-                        start_path_hashed(p, cam, x2, y, y * width + x2, sample_hash, p2);
+                        start_path_hashed(p, x2, y, y * width + x2, sample_hash, p2);
                         asm volatile("" ::"v"(p2.d.x), "v"(p2.d.y), "v"(p2.d.z), "v"(p2.seed));
                     }
 #endif
+#if RB_COLOR_COMBINE
+                    item = it | direct_mask;
+#else
                     item = it;
+#endif
                     if (p.u.max_depth > 0u) {
                         active = true;
                     } else {
@@ -320,12 +410,19 @@ __global__ void __launch_bounds__(kTraceBlock, RB_TRACE_WAVES) k_trace(const KPa
         if (active) {
             const bool alive = segment<STATS, MULTI>(p, pt, &s_stack[tid], kTraceBlock, tl);
             if (!alive) {
+#if RB_COLOR_COMBINE
+                cring.finish(colors, item, pt.color);
+#else
                 store_color(colors, item, pt.color);
+#endif
                 tl.paths++;
                 active = false;
             }
         }
     }
+#if RB_COLOR_COMBINE
+    for (uint32_t k = 0; k < kRingRows; k++) cring.drain(colors, lane, k);
+#endif
     flush_tally<STATS>(tl, p.counters);
 }
 
@@ -357,7 +454,6 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;
     const uint32_t sample_base = p.first_pass * p.samples_per_pass;
     const uint32_t node_count = p.u.bvh_node_count;
-    const Cam cam = make_cam(p);
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
     const cf4p nodes = (cf4p)p.nodes;
     const cf4p ptris = (cf4p)p.ptris;
@@ -403,7 +499,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
         // ---- (1) hand items to idle lanes
         iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
                   [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
-                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                      start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
                       item = it;
                       if (p.u.max_depth > 0u) {
                           state = BEGIN;
@@ -566,7 +662,8 @@ struct SphereWalkPolicy {
         st.uvx = st.uvy = 0.0f;
         st.use_tex = st.tri_won_a = false;
     }
-    DEV void begin(const KParams& p, const Path& pt, uint32_t* stack, Tally<STATS>& tl) {
+    DEV void begin(const KParams& p0, const Path& pt, uint32_t* stack, Tally<STATS>& tl) {
+        const KParams& p = fresh_params(p0);
         th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, kTraceBlock, tl);
         st = segment_pre<STATS>(p, pt, th, tl);
         w.begin(p, pt.o, pt.d, dot(pt.d, pt.d), st.closest_t);
@@ -582,7 +679,7 @@ struct SphereWalkPolicy {
         float closest_t = st.closest_t;
         uint32_t sphere_idx = 0xFFFFFFFFu;
         w.result(closest_t, sphere_idx);
-        return segment_post<STATS>(p, pt, th, st, closest_t, sphere_idx, tl);
+        return segment_post<STATS>(fresh_params(p), pt, th, st, closest_t, sphere_idx, tl);
     }
 };
 
@@ -597,7 +694,6 @@ DEV void trace_stepped(const KParams& p) {
     const uint32_t S = p.n_passes * p.samples_per_pass;
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;
     const uint32_t sample_base = p.first_pass * p.samples_per_pass;
-    const Cam cam = make_cam(p);
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
     uint32_t* const stack = &s_stack[tid];
     Tally<STATS> tl;
@@ -618,7 +714,7 @@ DEV void trace_stepped(const KParams& p) {
         // ---- (1) hand items to idle lanes
         iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
                   [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
-                      start_path_hashed(p, cam, x, y, y * width + x, sample_hash, pt);
+                      start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
                       item = it;
                       if (p.u.max_depth > 0u) {
                           state = BEGIN;
@@ -920,7 +1016,44 @@ uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu) {
     return device_cu_count_cached() * (blocks_per_cu ? blocks_per_cu : 8u) * 256u;  // k_trace / k_queue blocks are <= 256 threads
 }
 
-int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info, void* ev_after_trace) {
+// Cam for a launch: shader.wgsl:690,702-708 in the shader's operation order.  Host code of this file is compiled
+// with the same -ffp-contract=off, and +, -, *, /, sqrt of binary32 are correctly rounded on both sides, so these
+// are the values the kernels used to work out for themselves (the parity suite compares every frame with the oracle).
+static Cam host_cam(const rb_uniforms& u) {
+    struct V { float x, y, z; };
+    auto cross = [](V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+    auto normalize = [](V a) {
+        const float len = __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+        return V{a.x / len, a.y / len, a.z / len};
+    };
+    // ranges of rb_device_math.hpp's rcp_safe / div_safe_den
+    auto fast_den = [](float b) {
+        uint32_t x;
+        __builtin_memcpy(&x, &b, 4);
+        x &= 0x7FFFFFFFu;
+        return (x - 0x0D800000u) < 0x64000000u && (x - 0x21800000u) < 0x3C000000u && (x & 0x007FFFFFu) != 0x007FFFFFu;
+    };
+    Cam c{};
+    c.aspect = (float)u.width / (float)u.height;
+    const V fwd = normalize(V{u.camera.dir[0], u.camera.dir[1], u.camera.dir[2]});
+    const V right = normalize(cross(V{0.0f, 1.0f, 0.0f}, fwd));
+    const V up = cross(fwd, right);
+    for (int i = 0; i < 3; i++) c.pos[i] = u.camera.pos[i];
+    c.fwd[0] = fwd.x, c.fwd[1] = fwd.y, c.fwd[2] = fwd.z;
+    c.right[0] = right.x, c.right[1] = right.y, c.right[2] = right.z;
+    c.up[0] = up.x, c.up[1] = up.y, c.up[2] = up.z;
+    c.fov = u.camera.pane_width / (2.0f * u.camera.pane_distance * c.aspect);
+    c.wm1 = (float)(u.width - 1u);
+    c.hm1 = (float)(u.height - 1u);
+    c.fast_wh = (RB_FAST_DIV && fast_den(c.wm1) && fast_den(c.hm1)) ? 1u : 0u;
+    c.inv_wm1 = c.fast_wh ? 1.0f / c.wm1 : 0.0f;
+    c.inv_hm1 = c.fast_wh ? 1.0f / c.hm1 : 0.0f;
+    return c;
+}
+
+int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_, LaunchInfo* info, void* ev_after_trace) {
+    KParams p = p_;
+    p.cam = host_cam(p.u);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LaunchInfo li{};
     const size_t lds = sizeof(uint32_t) * p.stack_depth * 256u;
@@ -983,6 +1116,9 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
         batch = (batch / 64u) * 64u;
         if (batch < 64u) batch = 64u;
         if (batch > 4096u) batch = 4096u;
+        // k_trace combines its colour stores per 64-item row through a ring of kRingRows rows (ColorRing), which needs
+        // reservations of whole multiples of kRingRows rows; smaller launches keep their finer reservations and store directly
+        if (v == PLAIN && batch >= 128u) batch = batch < 256u ? 256u : (batch / 256u) * 256u;
         if (p.queue_batch) batch = p.queue_batch;
         q.queue_batch = (uint32_t)batch;
         {   // reciprocals for the item -> (tile, sample) -> (tx, ty) divisions (udiv_magic)
@@ -1021,6 +1157,7 @@ int launch_render(const KParams& p, uint32_t kernel, bool stats, void* stream_, 
                     else hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, stream, q);
                 } else {
                     if (stats) hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, stream, q);
+                    else if (items >= kTraceManyItems) hipLaunchKernelGGL((k_trace<false, false, 8>), grid, block, lds, stream, q);
                     else hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, stream, q);
                 }
                 break;

@@ -250,7 +250,10 @@ struct ColorRing {
 #ifndef RB_TRACE_WAVES
 #define RB_TRACE_WAVES 6
 #endif
-constexpr uint64_t kTraceManyItems = 1ull << 26;  // launches from here on take k_trace's 8-wave instantiation
+#ifndef RB_TRACE_WAVES_BIG
+#define RB_TRACE_WAVES_BIG 8
+#endif
+constexpr uint64_t kTraceManyItems = 3ull << 23;  // launches from here on take k_trace's 8-wave instantiation
 
 // The (pixel, sample) work queue of the stream kernels, one instance per wavefront.  The global
 // queue word is touched once per `batch` items (one word sustains only ~90 M atomics/s chip-wide);
@@ -261,7 +264,17 @@ struct ItemQueue {
     uint32_t loc_next = 0, loc_end = 0;  // this wave's reserved item range (wave-uniform)
     uint32_t batch;                      // items per reservation
     bool exhausted = false;
-    DEV explicit ItemQueue(uint32_t batch_) : batch(batch_) {}
+    // The first reservation is the wave's own: wave w starts on items [w * batch, (w + 1) * batch) and the queue word
+    // starts at waves * batch (launch_render), so a launch does not begin with every wave queueing for the one word
+    // (4096-8192 atomics at ~90 M/s: up to 45-90 us before the last wave had work).
+    DEV ItemQueue(uint32_t batch_, uint32_t total_items) : batch(batch_) {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint64_t first = (uint64_t)wave * batch_;
+        if (first < total_items) {
+            loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
+            loc_end = (total_items - loc_next < batch_) ? total_items : loc_next + batch_;
+        }
+    }
 
     DEV bool drained() const { return exhausted && loc_next == loc_end; }
 
@@ -329,6 +342,13 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
     uint32_t item = 0;
     uint32_t loc_next = 0, loc_end = 0;  // this wave's reserved item range (wave-uniform)
     const uint32_t batch = p.queue_batch;
+    {   // the first reservation is the wave's own (see ItemQueue)
+        const uint64_t first = (uint64_t)(blockIdx.x * (kTraceBlock / 64u) + (tid >> 6)) * batch;
+        if (first < total_items) {
+            loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
+            loc_end = (total_items - loc_next < batch) ? total_items : loc_next + batch;
+        }
+    }
     Path pt;
     pt.depth = 0;
 
@@ -484,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0;
-    ItemQueue iq(p.queue_batch);
+    ItemQueue iq(p.queue_batch, total_items);
     Path pt;
     pt.depth = 0;
     TriHit th;
@@ -701,7 +721,7 @@ DEV void trace_stepped(const KParams& p) {
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0;
-    ItemQueue iq(p.queue_batch);
+    ItemQueue iq(p.queue_batch, total_items);
     Path pt;
     pt.depth = 0;
     Walk w;
@@ -1109,16 +1129,19 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
         const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : dense;
         li.grid = persistent_blocks(items, li.block, blocks_per_cu);
         if (li.grid == 0) return 0;
-        // batch: >= 64 reservations per wave for balance, <= 4096 items, multiple of 64
+        // batch: the queue word sustains about 90 M atomics/s chip-wide, which 64-item reservations reach at 5-6 G
+        // items/s (C1 and C2 run there): about 8 reservations per wave, 64..512 items, a multiple of 64
+        // (profiles/r02_queue_batch.txt: C1 at 64 spp 17.1 -> 21.8 G segments/s)
         KParams q = p;
         const uint64_t waves = (uint64_t)li.grid * (li.block / 64u);
-        uint64_t batch = items / (waves * 64u);
+        // (the walks of trees and sphere sets hand out far fewer items per second: 64 reservations per wave, for balance)
+        uint64_t batch = items / (waves * (v == PLAIN ? 8u : 64u));
         batch = (batch / 64u) * 64u;
         if (batch < 64u) batch = 64u;
-        if (batch > 4096u) batch = 4096u;
+        if (batch > (v == PLAIN ? 512u : 4096u)) batch = (v == PLAIN ? 512u : 4096u);
         // k_trace combines its colour stores per 64-item row through a ring of kRingRows rows (ColorRing), which needs
         // reservations of whole multiples of kRingRows rows; smaller launches keep their finer reservations and store directly
-        if (v == PLAIN && batch >= 128u) batch = batch < 256u ? 256u : (batch / 256u) * 256u;
+        if (v == PLAIN && batch >= 256u) batch = (batch / 256u) * 256u;
         if (p.queue_batch) batch = p.queue_batch;
         q.queue_batch = (uint32_t)batch;
         {   // reciprocals for the item -> (tile, sample) -> (tx, ty) divisions (udiv_magic)
@@ -1126,7 +1149,9 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
             q.magic_S = S > 1u ? (uint32_t)((1ull << 32) / S) : 0xFFFFFFFFu;
             q.magic_tiles_x = tiles_x > 1u ? (uint32_t)((1ull << 32) / tiles_x) : 0xFFFFFFFFu;
         }
-        hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
+        // the queue starts behind the waves' own first reservations (ItemQueue)
+        const uint64_t queue_start = waves * batch;   // <= 8192 waves * 4096 items
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), (int)(uint32_t)queue_start, 1, stream);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(li.grid), block(li.block);
         switch (v) {
@@ -1157,7 +1182,7 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
                     else hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, stream, q);
                 } else {
                     if (stats) hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, stream, q);
-                    else if (items >= kTraceManyItems) hipLaunchKernelGGL((k_trace<false, false, 8>), grid, block, lds, stream, q);
+                    else if (items >= kTraceManyItems) hipLaunchKernelGGL((k_trace<false, false, RB_TRACE_WAVES_BIG>), grid, block, lds, stream, q);
                     else hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, stream, q);
                 }
                 break;

@@ -172,7 +172,7 @@ class Engine:
                  passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0,
                  no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False,
                  device_lbvh=False, reference_walk=False, host_bvh=False, devices=None, gather_peer_copy=False,
-                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False):
+                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0):
         """``devices`` (list of HIP ordinals): one handle over several devices of this process
         (rb_create_multi): rows sharded in stripes, one RCCL gather per delivered frame."""
         self._lib = load()
@@ -193,6 +193,7 @@ class Engine:
             | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0) | (abi.FLAG_SKIP_NEAR_DEGENERATE if skip_near_degenerate else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
+        opt._reserved[2] = queue_batch   # items a wave reserves per queue atomic (0 = the launcher's choice)
         opt._reserved[3] = 1 if no_leaf_stepping else 0   # ablation: per-segment traversal for multi-node trees
         opt._reserved[4] = int(lds_mode)   # LDS staging of small meshes: 0 = when it fits, 1 = never
         if devices is not None:

@@ -17,7 +17,7 @@ elif w == "lamp":
     s = _refscenes.ref_lamp(spp=spp)
 elif w == "c5s": s = scenes.mesh_scene(1024, 512, 1920, 1080, spp, 16, seed=11, with_blob=False)
 rc = RenderConfig.from_scene(s)
-eng = Engine.new(rc, kernel=kern, fast_bvh=bool(int(os.environ.get('RB_FAST', '0'))), skip_near_degenerate=bool(int(os.environ.get('RB_SKIP', '0'))), device_bvh=bool(int(os.environ.get('RB_DEVICE_BVH', '0'))), device_lbvh=bool(int(os.environ.get('RB_DEVICE_LBVH', '0'))), stats=bool(int(os.environ.get('RB_STATS', '0'))), lds_mode=int(os.environ.get('RB_LDS_MODE', '0')), no_leaf_stepping=bool(int(os.environ.get('RB_NO_STEP', '0'))), blocks_per_cu=int(os.environ.get('RB_BPC', '0'))); eng.update(rc)
+eng = Engine.new(rc, kernel=kern, fast_bvh=bool(int(os.environ.get('RB_FAST', '0'))), skip_near_degenerate=bool(int(os.environ.get('RB_SKIP', '0'))), device_bvh=bool(int(os.environ.get('RB_DEVICE_BVH', '0'))), device_lbvh=bool(int(os.environ.get('RB_DEVICE_LBVH', '0'))), stats=bool(int(os.environ.get('RB_STATS', '0'))), lds_mode=int(os.environ.get('RB_LDS_MODE', '0')), no_leaf_stepping=bool(int(os.environ.get('RB_NO_STEP', '0'))), blocks_per_cu=int(os.environ.get('RB_BPC', '0')), queue_batch=int(os.environ.get('RB_BATCH', '0'))); eng.update(rc)
 for _ in range(reps):
     eng.reset_stats(); eng.clear(); eng.dispatch(0, spp); eng.sync()
 st = eng.stats()

@@ -216,8 +216,9 @@ typedef struct rb_options {
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
     uint32_t _reserved[5];      /* tuning / ablation knobs, 0 = default: [0] persistent blocks per CU, [1] colour-buffer
-                                   budget in MiB (default 4096, at most half of the free device memory), [2] queue batch,
-                                   [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
+                                   budget in MiB (default 4096, at most half of the free device memory), [2] items a wave
+                                   reserves per queue atomic (a multiple of 64; multiples of 256 let the default kernel combine
+                                   its colour stores), [3] 1 = no leaf stepping, [4] LDS staging of small meshes (1 = never) */
 } rb_options;
 
 enum {
@@ -248,7 +249,7 @@ enum {
     RB_FLAG_NO_RUN_AHEAD = 256u, /* progressive iterator: do not start the next pass while a frame is read back */
     RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
-                                           (L^2 > 1.5e-3); a hit the reference reports from a near-zero determinant there can be
+                                           (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be
                                            missed.  Several times faster on coarse meshes; frames validated equal on the
                                            BASELINE scenes, but this is the one mode that is not proved exact. */
 };

@@ -315,7 +315,7 @@ struct ItemQueue {
 // MULTI = false: trees of at most one node only (the default instantiation: launch_render sends every multi-node
 // tree to a stepped kernel); MULTI = true: the per-segment ablation of those (opt no_leaf_stepping).
 // WAVES = resident waves per SIMD the register allocation aims for: 6 (80 registers, nothing spilled) except for the
-// large launches of the default instantiation, which run 0.5 % faster with 8 (64 registers, 9 spilled outside the
+// large launches of the default instantiation, which run 3 % faster with 8 (64 registers, 9 spilled outside the
 // segment code) -- and 2-3 % slower on one-sample frames, hence two instantiations.
 template <bool STATS, bool MULTI, int WAVES = RB_TRACE_WAVES>
 __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {

@@ -15,9 +15,11 @@ run c3
 run c3_ownhost --workload c3 --walk own-host
 run c3_ownhost_skip --workload c3 --walk own-host --skip-near-degenerate
 run lamp
+run lamp_ownhost --workload lamp --walk own-host
 run lamp_ownhost_skip --workload lamp --walk own-host --skip-near-degenerate
 # C5's 4096 spp take minutes per frame on one GPU in every mode: its geometry, resolution and depth at 32 spp
+# (default = the library's tree, built on the device, proved two-pass walk)
 run c5 --workload c5 --spp 32
-run c5_owndevice --workload c5 --spp 32 --walk own-device
+run c5_reference --workload c5 --spp 32 --walk reference
 run c5_owndevice_skip --workload c5 --spp 32 --walk own-device --skip-near-degenerate
 echo "=== iterator"; python3 tools/iter_rate.py > "gpurun_out/profiles_$tag/${tag}_iter_rate.txt" 2>&1; cat "gpurun_out/profiles_$tag/${tag}_iter_rate.txt"

@@ -423,7 +423,7 @@ struct FBuilder {
 
 // F_k of one triangle and whether it is "large" (see the comment above FBuilder), from the f32 edges the kernels
 // use.  The device builder gets the flag from slot_meta and repeats the arithmetic in double (rb_build.hip).
-TriBound tri_bound(const rb_gpu_triangle& t) {
+TriBound tri_bound(const rb_gpu_triangle& t, float small_cap) {
     double e1[3], e2[3], l1 = 0, l2 = 0;
     for (int a = 0; a < 3; ++a) {
         e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
@@ -439,7 +439,7 @@ TriBound tri_bound(const rb_gpu_triangle& t) {
     if (b.has_normal) {
         b.n[0] = nx / nn; b.n[1] = ny / nn; b.n[2] = nz / nn;
     }
-    b.large = !(cap <= double(kFastSmallCap));
+    b.large = !(cap <= double(small_cap));
     if (!b.large) b.f = static_cast<float>(cap * (1.0 + 1e-6));
     else if (b.has_normal) b.f = static_cast<float>(ll / nn / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5));   // 0.95: |a^| >= 0.95 |a| in the bound's range
     else b.f = std::numeric_limits<float>::infinity();
@@ -474,8 +474,9 @@ DCone merge(const DCone& a, const DCone& b_) {
 }  // namespace
 
 bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
-                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out) {
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out, float small_cap) {
     out = FastTree{};
+    out.small_cap = small_cap;
     if (node_count == 0 || index_len == 0) return false;
     // ---- reference visit order (right child first, shader.wgsl:376-387) and per-slot metadata
     out.ref_parent.assign(node_count, 0u);
@@ -495,7 +496,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 if (slot >= index_len) continue;                     // guard :331
                 if (indices[slot] >= tri_count) { ++rank; continue; }  // guard :336
                 if (out.slot_meta[slot * 2] != 0xFFFFFFFFu) return false;  // slot shared by two leaves: keep the reference walk
-                bound[slot] = tri_bound(tris[indices[slot]]);
+                bound[slot] = tri_bound(tris[indices[slot]], small_cap);
                 const bool large = bound[slot].large;
                 out.slot_meta[slot * 2] = ni;
                 out.slot_meta[slot * 2 + 1] = rank++ | (large ? kSlotLarge : 0u);
@@ -600,8 +601,8 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
 }
 
 bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
-                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out) {
-    if (!fast_bvh_prepare(tris, tri_count, indices, index_len, ref_nodes, node_count, out)) return false;
+                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out, float small_cap) {
+    if (!fast_bvh_prepare(tris, tri_count, indices, index_len, ref_nodes, node_count, out, small_cap)) return false;
     const std::vector<uint32_t> slots = std::move(out.slots);
     // ---- tight boxes per item; items are indices into `slots`
     const size_t n = slots.size();
@@ -609,7 +610,7 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < n; ++i) {
         const rb_gpu_triangle& t = tris[indices[slots[i]]];
-        q[i] = tri_bound(t).f;
+        q[i] = tri_bound(t, small_cap).f;
         for (int a = 0; a < 3; ++a) {
             bmn[i * 3 + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
             bmx[i * 3 + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));

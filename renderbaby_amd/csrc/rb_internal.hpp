@@ -55,7 +55,8 @@ constexpr float kFastGrazeCos = 0.03f;
 // culling margin of the library's tree then covers ALL its accepted hits, near-degenerate ones included, and the
 // second pass skips it.  16000 <=> L <= 0.126: a margin of at most 2.6e-2 of the distance to the box.  A tuning
 // constant, not part of the proof (any value up to 1.5e5 is covered): larger = fewer triangles left to the second
-// pass but wider margins in the first.  Measured (profiles/r02_small_cap_sweep.txt, M segments/s at 1500 / 8000 /
+// pass but wider margins in the first (with RB_FLAG_SKIP_NEAR_DEGENERATE there is no second pass to relieve and the
+// runtime passes 0: every triangle keeps the class (A) margin).  Measured (profiles/r02_small_cap_sweep.txt, M segments/s at 1500 / 8000 /
 // 16000 / 32000 / 64000 / 150000): C5 744 / 1603 / 1600 / 1608 / 1604 / 1601, reference lamp scene 669 / 750 / 1066 /
 // 1065 / 1102 / 909, C3 448 / 450 / 460 / 244 / 181 / 216.
 #ifndef RB_FAST_SMALL_CAP
@@ -83,7 +84,7 @@ struct TriBound {
     float f = 0.0f;            // F_k: bound of L^2 / |a^| over the hits the library's tree answers for
     bool large = false, has_normal = false;
 };
-TriBound tri_bound(const rb_gpu_triangle& t);
+TriBound tri_bound(const rb_gpu_triangle& t, float small_cap = kFastSmallCap);
 
 // The library's own triangle tree (rb_bvh.cpp).  Same 64-B two-box node as the sphere tree.
 struct FastTree {
@@ -98,13 +99,15 @@ struct FastTree {
     float margin = 0.0f;               // slab-rounding part of the box inflation
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};  // mesh bounds (for S, the per-ray distance bound)
     float root_amax = 0.0f;
+    float small_cap = kFastSmallCap;   // the "small triangle" threshold the per-triangle bounds were made with
 };
 bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
-                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out);
+                    const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, FastTree& out,
+                    float small_cap = kFastSmallCap);
 // The part of it that depends on the reference tree only: ref_parent, slot_meta, and `slots` = the
 // valid slots in the reference's visit order (the items a builder then arranges into a tree).
 bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
-                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out);
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out, float small_cap = kFastSmallCap);
 
 // ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
 struct DeviceTreeInfo {

@@ -550,11 +550,12 @@ int ensure_prepared(rb_engine* e) {
         e->fast_builder = "";
         // which builder: the device one from kDeviceBuildMinTriangles up (milliseconds instead of ~0.15 s per
         // million triangles), the host's binned SAH below; either can be forced
+        const float small_cap = (e->opt.flags & RB_FLAG_SKIP_NEAR_DEGENERATE) ? 0.0f : rb::kFastSmallCap;
         const bool force_host = (e->opt.flags & RB_FLAG_HOST_BVH) != 0u, force_dev = (e->opt.flags & RB_FLAG_DEVICE_BVH) != 0u;
         const bool try_device = !force_host && (force_dev || n_tris >= rb::kDeviceBuildMinTriangles);
         if (try_device) {
             // reference-order metadata on the host (one pass over the caller's tree), the tree on the device
-            if (rb::fast_bvh_prepare(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft) &&
+            if (rb::fast_bvh_prepare(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, ft, small_cap) &&
                 ft.slots.size() >= 1024) {
                 const uint32_t n = static_cast<uint32_t>(ft.slots.size());
                 DevBuf<uint32_t> visit_slots;
@@ -594,7 +595,7 @@ int ensure_prepared(rb_engine* e) {
         }
         if (!built) {
             if (!rb::fast_bvh_build(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes,
-                                    rb::kStackDepth, ft))
+                                    rb::kStackDepth, ft, small_cap))
                 return RB_OK;  // keep the reference walk
             rc = upload(e, e->fast_nodes, ft.nodes.data(), ft.nodes.size(), nullptr, true);
             if (!rc) rc = upload(e, e->fast_slots, ft.slots.data(), ft.slots.size(), nullptr, true);

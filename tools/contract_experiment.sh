@@ -10,6 +10,6 @@ rm -rf /tmp/csrc_fma && mkdir -p /tmp/csrc_fma/renderbaby_amd /tmp/csrc_fma/incl
 sed -i 's/#pragma clang fp contract(off)/#pragma clang fp contract(fast)/' /tmp/csrc_fma/renderbaby_amd/csrc/*.hpp /tmp/csrc_fma/renderbaby_amd/csrc/*.hip
 C=/tmp/csrc_fma/renderbaby_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -shared \
-  -o renderbaby_amd/librenderbaby_hip.so $C/rb_kernels.hip $C/rb_build.hip $C/rb_runtime.cpp $C/rb_bvh.cpp 2>/dev/null
+  -o renderbaby_amd/librenderbaby_hip.so $C/rb_kernels.hip $C/rb_build.hip $C/rb_runtime.cpp $C/rb_bvh.cpp $C/rb_rccl.cpp -ldl 2>/dev/null
 for r in 1 2; do echo "[contract fast] $(python tools/one_dispatch.py $args)"; done
 cp /tmp/lib_prod.so renderbaby_amd/librenderbaby_hip.so

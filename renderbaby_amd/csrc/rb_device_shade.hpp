@@ -166,7 +166,9 @@ struct SphereWalk {
             const uint32_t id = ids[j];
             if (n_tested) (*n_tested)++;
             const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-            if (t > 0.001f && (t < best || (t == best && id < best_id))) {
+            // strictly nearer than everything so far; equal t only displaces a SPHERE of higher index (the scan's order):
+            // a tie with the ground / triangle hit the walk started from loses, as in the reference (best_id still unset)
+            if (t > 0.001f && (t < best || (t == best && best_id != 0xFFFFFFFFu && id < best_id))) {
                 best = t;
                 best_id = id;
             }

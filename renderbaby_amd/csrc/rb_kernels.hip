@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 
     for (;;) {
         // ---- (1) hand items to idle lanes
-        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+        iq.refill(fresh_params(p), lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
                   [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
                       start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
                       item = it;
@@ -732,7 +732,7 @@ DEV void trace_stepped(const KParams& p) {
 
     for (;;) {
         // ---- (1) hand items to idle lanes
-        iq.refill(p, lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+        iq.refill(fresh_params(p), lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
                   [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
                       start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
                       item = it;

@@ -31,3 +31,23 @@ def test_random_scenes_all_variants(first):
             assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (seed, name)
             assert np.array_equal(frame.pixels, o_rgba), (seed, name)
             assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"], (seed, name)
+
+
+def test_sphere_at_exactly_the_t_of_an_earlier_category(monkeypatch):
+    # Found by the r02 fuzzer (FUZZ_BIG, seed 500188, pixel (54, 38)): a triangle and a sphere (of 90, so the
+    # library's sphere tree is in use) are hit at exactly the same t.  The reference's scan accepts a sphere only
+    # if t < closest.t, so the triangle stays; the tree's tie rule (lower index wins among spheres) used to let the
+    # first sphere displace it.  Whole frame, every variant.
+    monkeypatch.setenv("FUZZ_BIG", "1")
+    s = fuzz.random_scene(500188)
+    assert len(s.spheres) > 64 and (s.width, s.height) == (283, 199)
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    for name, kw in fuzz.variants(s):
+        e = Engine.new(rc, **kw)
+        frame = e.render(rc)
+        acc, st = e.read_accumulation(), e.stats()
+        e.close()
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), name
+        assert np.array_equal(frame.pixels, o_rgba), name
+        assert st["segments"] == o_st["segments"], name

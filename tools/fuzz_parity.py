@@ -116,7 +116,9 @@ def graze(sc, rng):
 
 def variants(scene):
     v = [("pixel", dict(kernel=abi.KERNEL_PIXEL, reference_walk=True)), ("queue", dict(kernel=abi.KERNEL_QUEUE, reference_walk=True)),
-         ("stream", dict(reference_walk=True))]
+         ("stream", dict(reference_walk=True)),
+         # k_trace's colour-store ring (reservations of 256 items) and its direct stores (64), whatever the frame size
+         ("stream-ring", dict(reference_walk=True, queue_batch=256)), ("stream-direct", dict(reference_walk=True, queue_batch=64))]
     if len(scene.bvh_nodes) > 1:
         v += [("stream-noLDS", dict(lds_mode=1, reference_walk=True)), ("stream-perseg", dict(no_leaf_stepping=True, reference_walk=True)),
               ("default", dict()), ("fast", dict(fast_bvh=True)),

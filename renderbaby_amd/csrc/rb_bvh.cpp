@@ -523,7 +523,7 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             // alpha = largest angle to it
             std::vector<std::array<double, 3>> nrm;
             bool ok = true;
-            for (uint32_t i = 0; i < n.primitive_count && ok; ++i) {
+            for (uint32_t i = 0; i < n.primitive_count; ++i) {   // every large triangle goes into gslots, cone or no cone
                 const uint32_t slot = n.first_primitive + i;
                 if (slot >= index_len || indices[slot] >= tri_count) continue;
                 const rb_gpu_triangle& t = tris[indices[slot]];

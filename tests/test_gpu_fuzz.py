@@ -51,3 +51,22 @@ def test_sphere_at_exactly_the_t_of_an_earlier_category(monkeypatch):
         assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), name
         assert np.array_equal(frame.pixels, o_rgba), name
         assert st["segments"] == o_st["segments"], name
+
+
+def test_second_pass_keeps_the_triangles_behind_a_degenerate_one(monkeypatch):
+    # Found by the r02 fuzzer (FUZZ_BIG, seed 603382, six pixels): the eye lies in the plane of a huge triangle, so the
+    # reference reports hits from a near-zero determinant that only the second pass of the library's walk can find.
+    # The list of a reference leaf's large triangles used to END at the first triangle without a normal (zero area),
+    # so every large triangle after it in the leaf was invisible to that pass.
+    monkeypatch.setenv("FUZZ_BIG", "1")
+    s = fuzz.random_scene(603382)
+    assert len(s.bvh_nodes) > 1
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    rc = RenderConfig.from_scene(s)
+    for name, kw in fuzz.variants(s):
+        e = Engine.new(rc, **kw)
+        frame = e.render(rc)
+        acc, st = e.read_accumulation(), e.stats()
+        e.close()
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), name
+        assert np.array_equal(frame.pixels, o_rgba), name

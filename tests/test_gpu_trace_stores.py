@@ -29,7 +29,7 @@ def test_ring_and_direct_stores_agree_with_the_oracle(size, spp, depth):
     # "deep-paths": at depth 40 some paths outlive four rows of their wave's ring and are sent to store directly.
     s = scenes.cornell(size[0], size[1], spp, depth)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
-    for batch in (256, 512, 64, 192, 0):
+    for batch in (256, 512, 64, 192, 0, 100, 1000, 16384):   # the last three: not multiples of a row / larger than the frame's share
         acc, px, st, name = _render(s, queue_batch=batch)
         assert name == "k_trace"
         assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), batch

@@ -247,6 +247,11 @@ enum {
     RB_FLAG_GATHER_PEER_COPY = 128u, /* rb_create_multi: move the stripes with hipMemcpyPeerAsync instead of RCCL
                                         (hosts without librccl; several shards on one device in the tests) */
     RB_FLAG_NO_RUN_AHEAD = 256u, /* progressive iterator: do not start the next pass while a frame is read back */
+    RB_FLAG_CHUNK_WALK = 1024u, /* multi-node meshes: the chunked walk -- the caller's tree walked with the reference's own
+                                   slab arithmetic (nearer child first, subtrees culled on the best t by the margin that
+                                   bounds the reference's reported hits), the library's own levels below its leaves down
+                                   to 16-triangle chunks, which a wavefront tests cooperatively, one triangle per lane
+                                   (DESIGN.md section 4.2); same frames */
     RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
                                            (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be

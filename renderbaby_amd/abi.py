@@ -70,6 +70,7 @@ FLAG_HOST_BVH = 64
 FLAG_GATHER_PEER_COPY = 128
 FLAG_NO_RUN_AHEAD = 256
 FLAG_SKIP_NEAR_DEGENERATE = 512
+FLAG_CHUNK_WALK = 1024
 COMM_ID_BYTES = 128
 
 

@@ -637,4 +637,247 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
     return out.depth <= stack_limit;
 }
 
+
+// ------------------------------------------------------------ the chunked walk's tree (ChunkTree) --
+// The caller's tree on top -- every reference node becomes one two-box node whose child slots carry the children's
+// reference boxes bit for bit, so the kernel can repeat shader.wgsl:664-671 on them -- and below every reference
+// leaf a small median-split tree of the library's own (tight f32 boxes) down to chunks of at most kChunkTris
+// triangles.  Per child slot, rounded outwards: the two bounds of L^2 / |a^| (tri_bound: the determinant floor, which
+// covers every accepted hit, and the |cos| >= c0 bound, far smaller) and the cone of the normals below, which tells
+// the walk which of the two a given ray needs.  Triangles are renumbered chunk by chunk; the reference's visit order
+// survives as the rank that breaks ties in t.
+namespace {
+struct ChunkInfo {
+    uint32_t ref = kChunkNone;
+    double cap = 0.0, fa = 0.0;
+    DCone cone;
+    uint32_t depth = 0;   // internal nodes on the longest path below (= stack entries the walk may need)
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};   // tight bounds of the triangles below
+};
+struct ChunkItem {
+    uint32_t slot, rank;
+    float mn[3], mx[3];
+    double cap, fa;
+    double n[3];
+    bool has_normal;
+};
+DCone empty_cone() {
+    DCone c;
+    c.valid = true;
+    c.alpha = -1.0;
+    c.c[0] = 1.0;
+    return c;
+}
+DCone merge_cones(const DCone& a, const DCone& b) {
+    if (a.valid && a.alpha < 0.0) return b;
+    if (b.valid && b.alpha < 0.0) return a;
+    return merge(a, b);
+}
+// direct cone of a handful of normals (either orientation): axis = normalised sum of the sign-aligned normals
+DCone cone_of(const ChunkItem* it, size_t n) {
+    DCone c;
+    if (n == 0) return empty_cone();
+    double sum[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        if (!it[i].has_normal) return c;   // no normal: any direction grazes it
+        const double sg = (it[i].n[0] * it[0].n[0] + it[i].n[1] * it[0].n[1] + it[i].n[2] * it[0].n[2]) < 0.0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; ++a) sum[a] += sg * it[i].n[a];
+    }
+    const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+    if (!(len > 1e-9)) return c;
+    double cmin = 1.0;
+    for (int a = 0; a < 3; ++a) c.c[a] = sum[a] / len;
+    for (size_t i = 0; i < n; ++i) cmin = std::min(cmin, std::fabs(it[i].n[0] * c.c[0] + it[i].n[1] * c.c[1] + it[i].n[2] * c.c[2]));
+    c.alpha = std::acos(std::min(1.0, cmin)) + 1e-9;
+    c.valid = c.alpha < 1.55;
+    return c;
+}
+// {axis cos(alpha), tan(alpha)} as FastWalk::graze_possible reads it; all zeros = "any ray may graze a triangle below"
+void encode_cone(const DCone& c, float o[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.0f;
+    if (!c.valid) return;
+    if (c.alpha < 0.0) { o[3] = -1.0f; return; }   // nothing below
+    const double cos_a = std::cos(c.alpha) * (1.0 - 1e-6) - 1e-7;
+    if (!(cos_a > 0.0175)) return;
+    const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
+    o[0] = static_cast<float>(c.c[0] * cos_a);
+    o[1] = static_cast<float>(c.c[1] * cos_a);
+    o[2] = static_cast<float>(c.c[2] * cos_a);
+    o[3] = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
+}
+// v >= 0 as bf16, rounded up; beyond 1.5e5 (where the bound is not claimed) +inf
+uint32_t bf16_up(double v) {
+    if (!(v <= 1.5e5)) return 0x7F80u;
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    return (b >> 16) + ((b & 0xFFFFu) ? 1u : 0u);
+}
+uint32_t pack_fac(const ChunkInfo& i) { return (bf16_up(i.cap * (1.0 + 1e-6)) << 16) | bf16_up(i.fa); }
+
+struct ChunkBuilder {
+    ChunkTree& out;
+    std::vector<ChunkItem>& items;
+
+    void fill_child(const ChunkInfo& i, const float mn[3], const float mx[3], float bmin[3], uint32_t& ref, float bmax[3],
+                    uint32_t& fac, float cone[4]) const {
+        std::memcpy(bmin, mn, 12);
+        std::memcpy(bmax, mx, 12);
+        ref = i.ref;
+        fac = pack_fac(i);
+        // the margins bound the distance of a reported hit from its TRIANGLE; culling on a box needs the triangles
+        // inside it.  The reference's builder guarantees that (bvh.rs:100-123), a caller's own tree need not: such a
+        // child is always entered (its reference box still decides, exactly, whether the leaf below is reached)
+        for (int a = 0; a < 3; ++a)
+            if (i.ref != kChunkNone && !(mn[a] <= i.mn[a] && i.mx[a] <= mx[a])) fac = 0x7F807F80u;
+        encode_cone(i.cone, cone);
+    }
+    void tight(size_t lo, size_t hi, float mn[3], float mx[3]) const {
+        for (int a = 0; a < 3; ++a) { mn[a] = kInf; mx[a] = -kInf; }
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], items[i].mn[a]);
+                mx[a] = std::max(mx[a], items[i].mx[a]);
+            }
+    }
+    // the library's own levels below one reference leaf: items [lo, hi)
+    ChunkInfo build(size_t lo, size_t hi) {
+        const size_t count = hi - lo;
+        ChunkInfo r;
+        if (count <= kChunkTris) {
+            const uint32_t first = static_cast<uint32_t>(out.pos_slot.size());
+            for (size_t i = lo; i < hi; ++i) {
+                out.pos_slot.push_back(items[i].slot);
+                out.pos_rank.push_back(items[i].rank);
+                r.cap = std::max(r.cap, items[i].cap);
+                r.fa = std::max(r.fa, items[i].fa);
+            }
+            tight(lo, hi, r.mn, r.mx);
+            r.cone = cone_of(&items[lo], count);
+            r.ref = kChunkLeaf | (static_cast<uint32_t>(count - 1) << 26) | first;
+            return r;
+        }
+        // k chunks in the end; the left half gets floor(k / 2) of them: sizes stay within one of count / k
+        const size_t k = (count + kChunkTris - 1) / kChunkTris, kl = k / 2;
+        const size_t mid = lo + std::max<size_t>(1, count * kl / k);
+        float cmn[3] = {kInf, kInf, kInf}, cmx[3] = {-kInf, -kInf, -kInf};
+        auto centroid = [&](const ChunkItem& it, int a) { return 0.5f * (it.mn[a] + it.mx[a]); };
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                cmn[a] = std::min(cmn[a], centroid(items[i], a));
+                cmx[a] = std::max(cmx[a], centroid(items[i], a));
+            }
+        const float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
+        const int axis = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [&](const ChunkItem& x, const ChunkItem& y) { return centroid(x, axis) < centroid(y, axis); });
+        const ChunkInfo l = build(lo, mid), rr = build(mid, hi);
+        ChunkNode n{};
+        float mn[3], mx[3];
+        tight(lo, mid, mn, mx);
+        fill_child(l, mn, mx, n.lmin, n.lref, n.lmax, n.lfac, n.lcone);
+        tight(mid, hi, mn, mx);
+        fill_child(rr, mn, mx, n.rmin, n.rref, n.rmax, n.rfac, n.rcone);
+        r.ref = static_cast<uint32_t>(out.nodes.size());   // children carry the library's own boxes: no kChunkExact
+        out.nodes.push_back(n);
+        r.cap = std::max(l.cap, rr.cap);
+        r.fa = std::max(l.fa, rr.fa);
+        r.cone = merge_cones(l.cone, rr.cone);
+        r.depth = 1 + std::max(l.depth, rr.depth);
+        tight(lo, hi, r.mn, r.mx);
+        return r;
+    }
+};
+}  // namespace
+
+bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, ChunkTree& out) {
+    out = ChunkTree{};
+    if (node_count < 2 || index_len == 0 || ref_nodes[0].primitive_count > 0) return false;
+    // ---- the reference's visit order (right child first, shader.wgsl:376-387): ranks, and nodes parents-first
+    std::vector<uint32_t> order, st{0u}, leaf_rank0(node_count, 0u);
+    uint32_t rank = 0;
+    while (!st.empty()) {
+        const uint32_t ni = st.back();
+        st.pop_back();
+        order.push_back(ni);
+        const rb_bvh_node& n = ref_nodes[ni];
+        if (n.primitive_count > 0) {
+            leaf_rank0[ni] = rank;
+            for (uint32_t i = 0; i < n.primitive_count; ++i) {
+                const uint32_t slot = n.first_primitive + i;
+                if (slot >= index_len || indices[slot] >= tri_count) continue;   // guards :331, :336
+                out.rank_slot.push_back(slot);
+                ++rank;
+            }
+        } else {
+            if (n.left < node_count) st.push_back(n.left);
+            if (n.right < node_count) st.push_back(n.right);
+        }
+    }
+    if (rank == 0 || rank >= (1u << 26) - 64u || order.size() > node_count) return false;
+    // ---- bottom-up: children before parents
+    std::vector<ChunkInfo> info(node_count);
+    std::vector<ChunkItem> items;
+    ChunkBuilder cb{out, items};
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t ni = order[k];
+        const rb_bvh_node& n = ref_nodes[ni];
+        ChunkInfo& r = info[ni];
+        if (n.primitive_count > 0) {
+            items.clear();
+            uint32_t rk = leaf_rank0[ni];
+            for (uint32_t i = 0; i < n.primitive_count; ++i) {
+                const uint32_t slot = n.first_primitive + i;
+                if (slot >= index_len || indices[slot] >= tri_count) continue;
+                const rb_gpu_triangle& t = tris[indices[slot]];
+                ChunkItem it;
+                it.slot = slot;
+                it.rank = rk++;
+                double ll = 0, l2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    it.mn[a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
+                    it.mx[a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
+                    ll += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
+                    l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
+                }
+                const TriBound b = tri_bound(t, 0.0f);   // threshold 0: every triangle keeps its |cos| >= c0 bound
+                it.cap = std::max(ll, l2) * 1e6 * (1.0 + 1e-5);
+                it.fa = b.f;
+                it.has_normal = b.has_normal;
+                for (int a = 0; a < 3; ++a) it.n[a] = b.n[a];
+                items.push_back(it);
+            }
+            if (!items.empty()) r = cb.build(0, items.size());
+        } else {
+            const bool hl = n.left < node_count, hr = n.right < node_count;
+            const ChunkInfo none;
+            const ChunkInfo& l = hl ? info[n.left] : none;
+            const ChunkInfo& rr = hr ? info[n.right] : none;
+            if (l.ref == kChunkNone && rr.ref == kChunkNone) continue;   // nothing to hit below
+            ChunkNode c{};
+            const float zero[3] = {0, 0, 0};
+            cb.fill_child(l, hl ? ref_nodes[n.left].aabb_min : zero, hl ? ref_nodes[n.left].aabb_max : zero, c.lmin, c.lref, c.lmax,
+                          c.lfac, c.lcone);
+            cb.fill_child(rr, hr ? ref_nodes[n.right].aabb_min : zero, hr ? ref_nodes[n.right].aabb_max : zero, c.rmin, c.rref,
+                          c.rmax, c.rfac, c.rcone);
+            r.ref = static_cast<uint32_t>(out.nodes.size()) | kChunkExact;
+            out.nodes.push_back(c);
+            r.cap = std::max(l.cap, rr.cap);
+            r.fa = std::max(l.fa, rr.fa);
+            r.cone = merge_cones(l.ref == kChunkNone ? empty_cone() : l.cone, rr.ref == kChunkNone ? empty_cone() : rr.cone);
+            r.depth = 1 + std::max(l.depth, rr.depth);
+            for (int a = 0; a < 3; ++a) {
+                r.mn[a] = std::min(l.mn[a], rr.mn[a]);
+                r.mx[a] = std::max(l.mx[a], rr.mx[a]);
+            }
+        }
+    }
+    out.root = info[0].ref;
+    out.depth = info[0].depth;
+    if (out.root == kChunkNone || out.nodes.size() >= (1u << 30)) return false;
+    return out.depth + 1u <= stack_limit;
+}
+
 }  // namespace rb

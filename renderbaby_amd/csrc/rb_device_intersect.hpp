@@ -259,6 +259,17 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 //     margin = Sp (27 u FA + 20 u),
 // and X is inside the box so inflated, entered no later than t^: the slab test with that margin and the cull
 // `entry > best t` are safe.
+// Can a triangle whose normal lies in `cone` = {c cos(alpha), tan(alpha)} (every unit normal below is within alpha of
+// +-c) have |cos(d, n)| < c0?  |cos(d, n)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with x = |d . c|.  y = x cos(alpha)
+// is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible; tan(alpha) = -1 = nothing below = never.
+DEV bool cone_admits_grazing(f3 d, v4f cone) {
+    if (cone.w < 0.0f) return false;
+    const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
+    const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
+    const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);
+    const float lb = __builtin_fmaf(-cone.w, root, y - 1e-6f);
+    return !(lb >= kFastGrazeCos);
+}
 constexpr float kFastKF = 27.0f * 5.9604645e-8f * 1.01f;
 constexpr float kFastKS = 20.0f * 5.9604645e-8f * 1.01f;
 template <bool STATS>
@@ -349,14 +360,7 @@ struct FastWalk {
     // every unit normal below is within alpha of +-c, so |cos(d, n)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with
     // x = |d . c|.  y = x cos(alpha) is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible;
     // tan(alpha) = -1 = no large triangle below = never.
-    DEV bool graze_possible(v4f cone) const {
-        if (cone.w < 0.0f) return false;   // no large triangle below this node
-        const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
-        const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
-        const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);
-        const float lb = __builtin_fmaf(-cone.w, root, y - 1e-6f);
-        return !(lb >= kFastGrazeCos);
-    }
+    DEV bool graze_possible(v4f cone) const { return cone_admits_grazing(d, cone); }
     // The second pass: the reference's own walk (shader.wgsl:309-389: same nodes, same slab arithmetic, so a leaf
     // is reached exactly when the reference tests its triangles), restricted to nodes that can hold a class-(B)
     // triangle, and in a leaf to the triangles that are class (B) for this ray (the prepared unit normal is the

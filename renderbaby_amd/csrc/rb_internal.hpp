@@ -109,6 +109,39 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
 bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                       const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out, float small_cap = kFastSmallCap);
 
+// ---- The chunked walk (k_trace_chunk): the caller's tree on top, walked with the reference's
+// own slab arithmetic on the reference's boxes (so a leaf is reached exactly when shader.wgsl:309-389 reaches it),
+// nearer child first, and below every reference leaf the library's own small tree down to chunks of at most
+// kChunkTris triangles, which a wavefront then tests cooperatively (one triangle per lane, coalesced records).
+// A subtree is skipped only when the ray misses its box inflated by the margin that bounds how far from its
+// triangle the reference's f32 Moller-Trumbore can report a hit (rb_device_intersect.hpp, FastWalk::entry), or
+// enters it beyond the best t.  One 96-B node decides both children:
+struct alignas(16) ChunkNode {
+    float lmin[3];
+    uint32_t lref;   // child reference: kChunkNone | leaf = bit 31, (count - 1) << 26, first position | node index, bit 30 = that node's children carry reference boxes
+    float lmax[3];
+    uint32_t rref;
+    float rmin[3];
+    uint32_t lfac;   // two bf16, rounded up: high = largest L^2 / 1e-6 below the child (bounds EVERY accepted hit), low = largest
+    float rmax[3];   //   (L^2 / N) / (0.95 c0) (bounds the hits with |cos(ray, normal)| >= c0); 0x7F80 = +inf = always enter
+    uint32_t rfac;
+    float lcone[4];  // {axis cos(alpha), tan(alpha)} of the normals below the child (GrazeNode::cone): which of the two applies
+    float rcone[4];
+};
+static_assert(sizeof(ChunkNode) == 96, "ChunkNode is 96 B");
+constexpr uint32_t kChunkTris = 16;           // triangles per chunk = lanes per (ray, chunk) unit
+constexpr uint32_t kChunkNone = 0xFFFFFFFFu;
+constexpr uint32_t kChunkLeaf = 0x80000000u, kChunkExact = 0x40000000u;
+struct ChunkTree {
+    std::vector<ChunkNode> nodes;
+    std::vector<uint32_t> pos_slot;    // chunk order -> slot in bvh_indices order
+    std::vector<uint32_t> pos_rank;    // chunk order -> rank in the reference's visit order (ties in t go to the lower rank)
+    std::vector<uint32_t> rank_slot;   // rank -> slot (the winner's record for shading)
+    uint32_t root = kChunkNone, depth = 0;
+};
+bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, ChunkTree& out);
+
 // ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
 struct DeviceTreeInfo {
     uint32_t root, depth;
@@ -185,6 +218,13 @@ struct KParams {
     float fast_root_amax;
     float fast_bmax[3];
     uint32_t _pad_fast;
+    const ChunkNode* chunk_nodes;  // the chunked walk's tree (nullptr => another walk)
+    const float* chunk_a;          // float4 per chunk-order position: v0, rank (as bits)
+    const float* chunk_b;          // float4: e1, -
+    const float* chunk_c;          // float4: e2, -
+    const uint32_t* chunk_rank_slot; // rank -> slot
+    uint32_t chunk_root;           // root child reference (the root's own box is nodes[0]'s)
+    uint32_t chunk_n;              // positions
     const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
     const float* sph_leaf;         // float4 {centre, radius} in leaf order
     const uint32_t* sph_id;        // original sphere index per leaf-order slot
@@ -229,6 +269,9 @@ int launch_prep_tris(const rb_gpu_triangle* tris, uint32_t tri_count, const uint
                      uint32_t index_len, PrepTri* out, PrepTriShade* shade, void* stream);
 int launch_prep_materials(void* first_material, uint32_t stride, uint32_t n, void* stream);
 int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, PrepTri* out, void* stream);
+// prepared triangles -> the chunked walk's three float4 arrays in chunk order (A: v0 | rank, B: e1, C: e2)
+int launch_chunk_gather(const PrepTri* ptris, const uint32_t* pos_slot, const uint32_t* pos_rank, uint32_t n, float* a,
+                        float* b, float* c, void* stream);
 // Multi-GPU assembly on the root device: gathered[rank][local row][x] (every rank's padded stripe buffer back to
 // back) -> frame[global row][x]
 int launch_deinterleave(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t padded_rows,

@@ -614,6 +614,254 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     flush_tally<STATS>(tl, p.counters);
 }
 
+// ======================================================= kernel: CHUNK ====
+// The chunked walk (rb_internal.hpp, ChunkNode).  Two shapes of work alternate inside one
+// persistent wavefront:
+//   lane = RAY for the tree: every lane walks its own ray down the two-box nodes, nearer child first.  Nodes made from
+//     the caller's tree carry the reference's boxes and are entered only if the reference's own slab test passes
+//     (shader.wgsl:664-671, same operations) -- so a reference leaf is reached exactly when intersect_bvh reaches it --
+//     and, like the library's own levels below the reference leaves, only if the ray enters the box, inflated by the
+//     margin that bounds how far from its triangle the reference can report a hit, no later than the best t so far;
+//   lane = TRIANGLE for the leaves: the (ray, chunk) pairs of all 64 lanes are pooled, and every round four of them
+//     are tested by 16 lanes each -- one triangle per lane, records read as consecutive 16-byte pieces of three
+//     arrays (a wavefront's load touches 4 x 256 B instead of 64 scattered records), the ray fetched from LDS, the
+//     reference's intersect_triangle unchanged -- and a hit goes to its ray's best key with one LDS atomic min on
+//     (t, rank in the reference's visit order): the reference's strict `t < closest` in visit order is exactly the
+//     lexicographic minimum.
+// A lane whose stack runs empty is shaded (segment_finish) and starts its next segment or a new path while the others
+// keep walking, as in the other stepped kernels.
+#ifndef RB_CHUNK_WAVES
+#define RB_CHUNK_WAVES 4
+#endif
+#ifndef RB_CHUNK_NODE_LANES
+#define RB_CHUNK_NODE_LANES 20   // keep stepping nodes while this many lanes are at one ...
+#endif
+#ifndef RB_CHUNK_NODE_STEPS
+#define RB_CHUNK_NODE_STEPS 6    // ... but at most this many steps per outer iteration
+#endif
+#ifndef RB_CHUNK_LEAF_LANES
+#define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)
+#endif
+#ifndef RB_CHUNK_FINISH_LANES
+#define RB_CHUNK_FINISH_LANES 12 // shade once this many lanes have finished their walk (or nobody walks)
+#endif
+constexpr float kChunkKF = 27.0f * 5.9604645e-8f * 1.01f;   // FastWalk's margin, with 4 u more for the slab arithmetic
+constexpr float kChunkKS = 24.0f * 5.9604645e-8f * 1.01f;   // done on the uninflated box (chunk_child)
+constexpr uint32_t kChunkWaveLds = 64u * 32u + 64u * 8u + 64u * 4u;   // per wave: ray records, best keys, unit table
+constexpr unsigned long long kChunkNoHit = 0x60AD78EC00000000ull;     // (bits of 1e20f) << 32: shader.wgsl:283-290
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+
+// One child slot of a ChunkNode: enter it?  `order` = where the ray enters the inflated box (nearer child first).
+// The slab values are the reference's (shader.wgsl:664-671 on the box as stored); the inflated box is derived from
+// them per axis -- a box grown by mm enters mm |1 / d| earlier and leaves as much later -- so one set of operations
+// serves the exact test and the conservative one.  NaN (0 * inf) always means "enter".
+DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f3 d, f3 inv, float best_t, float& order) {
+    const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
+    const f3 t0 = a * inv, t1 = b * inv;
+    const float nx = fminf(t0.x, t1.x), ny = fminf(t0.y, t1.y), nz = fminf(t0.z, t1.z);
+    const float fx = fmaxf(t0.x, t1.x), fy = fmaxf(t0.y, t1.y), fz = fmaxf(t0.z, t1.z);
+    const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
+    if (exact && !(tmax >= fmaxf(tmin, 0.0f))) return false;   // the reference does not enter this node
+    // which bound of L^2 / |a^| this ray needs below the child: the determinant floor if it may graze a triangle there
+    const float f = cone_admits_grazing(d, cone) ? __uint_as_float(fac & 0xFFFF0000u) : __uint_as_float(fac << 16);
+    // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
+    const float mx = fmaxf(fabsf(a.x), fabsf(b.x)), my = fmaxf(fabsf(a.y), fabsf(b.y)), mz = fmaxf(fabsf(a.z), fabsf(b.z));
+    const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz))) +
+                      2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+    const float mm = (f <= 1.5e5f) ? sp_ * __builtin_fmaf(kChunkKF, f, kChunkKS) : 1e30f;   // NaN -> 1e30
+    const float ix = fabsf(inv.x), iy = fabsf(inv.y), iz = fabsf(inv.z);
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
+    const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fx), __builtin_fmaf(mm, iy, fy)), __builtin_fmaf(mm, iz, fz));
+    order = tn;
+    return !(tf < fmaxf(tn, 0.0f)) && !(tn > best_t);
+}
+
+// cur is an internal node: descend into the nearer child that is entered, remember the other.  False when the walk is complete.
+template <bool STATS>
+DEV bool chunk_node_step(const KParams& p, uint32_t* stack, uint32_t stride, f3 o, f3 d, f3 inv, float best_t, uint32_t& cur,
+                         int& sp, Tally<STATS>& tl) {
+    const bool exact = (cur & kChunkExact) != 0u;
+    const cf4p q = (cf4p)p.chunk_nodes + (size_t)(cur & 0x3FFFFFFFu) * 6u;
+    const v4f l0 = q[0], l1 = q[1], r0 = q[2], r1 = q[3], lc = q[4], rc = q[5];
+    const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+    float kl = 0.0f, kr = 0.0f;
+    if constexpr (STATS) tl.nodes += (lref != kChunkNone ? 1u : 0u) + (rref != kChunkNone ? 1u : 0u);
+    const bool vl = lref != kChunkNone && chunk_child(l0, l1, __float_as_uint(r0.w), lc, exact, o, d, inv, best_t, kl);
+    const bool vr = rref != kChunkNone && chunk_child(r0, r1, __float_as_uint(r1.w), rc, exact, o, d, inv, best_t, kr);
+    if (vl && vr) {
+        const bool left_first = !(kr < kl);
+        stack[sp * stride] = left_first ? rref : lref;
+        sp++;
+        cur = left_first ? lref : rref;
+        return true;
+    }
+    if (vl || vr) {
+        cur = vl ? lref : rref;
+        return true;
+    }
+    if (sp == 0) return false;
+    sp--;
+    cur = stack[sp * stride];
+    return true;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const uint32_t total_items = tiles_x * tiles_y * S * 64u;
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
+    uint32_t* const stack = &s_stack[tid];
+    Tally<STATS> tl;
+    // this wave's corner of LDS behind the traversal stacks
+    unsigned char* const wl = reinterpret_cast<unsigned char*>(s_stack + p.stack_depth * kTraceBlock) + (tid >> 6) * kChunkWaveLds;
+    lds_v4f* const rayrec = (lds_v4f*)wl;                    // [64][2]: {o, chunk reference}, {d, -}
+    lds_u64* const best = (lds_u64*)(wl + 64u * 32u);        // [64]: (t bits) << 32 | rank
+    lds_u32* const units = (lds_u32*)(wl + 64u * 40u);       // [64]: ray lane of every pooled (ray, chunk) pair
+
+    enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
+    uint32_t state = IDLE;
+    uint32_t item = 0, cur = 0;
+    ItemQueue iq(p.queue_batch, total_items);
+    Path pt;
+    pt.depth = 0;
+    f3 inv = mk(0, 0, 0);
+    unsigned long long key = kChunkNoHit;
+    int sp = 0;
+
+    for (;;) {
+        // ---- (1) hand items to idle lanes
+        iq.refill(fresh_params(p), lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
+                      start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
+                      item = it;
+                      if (p.u.max_depth > 0u) {
+                          state = BEGIN;
+                      } else {
+                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                          tl.paths++;
+                      }
+                  });
+        if (__ballot(state != IDLE) == 0ull) {
+            if (iq.drained()) break;
+            continue;
+        }
+
+        // ---- (2) start of a segment: the root's own box (shader.wgsl:283-315), then its two children
+        if (state == BEGIN) {
+            const KParams& fp = fresh_params(p);
+            inv = mk(rcp_exact(pt.d.x), rcp_exact(pt.d.y), rcp_exact(pt.d.z));
+            key = kChunkNoHit;
+            sp = 0;
+            const cf4p rn = (cf4p)fp.nodes;
+            const v4f n0 = rn[0], n1 = rn[1];
+            if constexpr (STATS) tl.nodes++;
+            if (isect_aabb(pt.o, inv, mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z))) {
+                cur = fp.chunk_root;
+                state = TRAV;
+            } else {
+                state = FINISH;
+            }
+        }
+
+        // ---- (3) tree: a few node steps while enough lanes are at a node
+        for (int it = 0; it < RB_CHUNK_NODE_STEPS; ++it) {
+            const bool at_node = state == TRAV && (cur & kChunkLeaf) == 0u;
+            const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
+            if (n == 0u || (it > 0 && n < (uint32_t)RB_CHUNK_NODE_LANES)) break;
+            if (at_node && !chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl))
+                state = FINISH;
+        }
+
+        // ---- (4) leaves: pool the (ray, chunk) pairs of the lanes that wait at a chunk, 16 lanes per pair
+        {
+            const bool lf = state == TRAV && (cur & kChunkLeaf) != 0u;
+            const unsigned long long m = __ballot(lf);
+            const uint32_t n_units = (uint32_t)__popcll(m);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && !lf));
+            if (n_units != 0u && (n_units >= (uint32_t)RB_CHUNK_LEAF_LANES || n_node == 0u)) {
+                if (lf) {
+                    units[(uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lane;
+                    const v4f r0 = {pt.o.x, pt.o.y, pt.o.z, __uint_as_float(cur)}, r1 = {pt.d.x, pt.d.y, pt.d.z, 0.0f};
+                    rayrec[lane * 2u] = r0;
+                    rayrec[lane * 2u + 1u] = r1;
+                    best[lane] = key;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const cf4p ca = (cf4p)p.chunk_a, cb = (cf4p)p.chunk_b, cc = (cf4p)p.chunk_c;
+                for (uint32_t g0 = 0; g0 < n_units; g0 += 4u) {
+                    const uint32_t g = g0 + (lane >> 4);
+                    const bool ok = g < n_units;
+                    const uint32_t rl = units[ok ? g : 0u];
+                    const v4f r0 = rayrec[rl * 2u], r1 = rayrec[rl * 2u + 1u];
+                    const uint32_t ref = __float_as_uint(r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
+                    const uint32_t j = lane & 15u;
+                    const bool valid = ok && j < cnt;
+                    const uint32_t pos = first + (j < cnt ? j : 0u);
+                    const v4f a = ca[pos], b = cb[pos], c = cc[pos];
+                    if constexpr (STATS) tl.tris += valid ? 1u : 0u;
+                    float u, v;
+                    const float t = isect_triangle(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(a.x, a.y, a.z), mk(b.x, b.y, b.z),
+                                                   mk(c.x, c.y, c.z), u, v);
+                    if (valid && t > 0.001f) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(a.w);
+                        __hip_atomic_fetch_min(&best[rl], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if constexpr (STATS) tl.mesh_hits++;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lf) {
+                    key = best[lane];
+                    if (sp == 0) {
+                        state = FINISH;
+                    } else {
+                        sp--;
+                        cur = stack[sp * kTraceBlock];
+                    }
+                }
+            }
+        }
+
+        // ---- (5) finished walks: the winner's record, the rest of the segment (shading), next ray
+        {
+            const uint32_t n_fin = (uint32_t)__popcll(__ballot(state == FINISH));
+            const uint32_t n_trav = (uint32_t)__popcll(__ballot(state == TRAV));
+            if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u) && state == FINISH) {
+                TriHit th;
+                th.hit = key != kChunkNoHit;
+                th.t = 1e20f;
+                th.u = th.v = 0.0f;
+                th.slot = 0u;
+                if (th.hit) {
+                    // (t, u, v) of the winner again from its prepared record: the same operations on the same values
+                    const KParams& fp = fresh_params(p);
+                    th.slot = cptr(fp.chunk_rank_slot)[(uint32_t)key];
+                    const cf4p tp = (cf4p)fp.ptris + (size_t)th.slot * 4u;
+                    const v4f a = tp[0], b = tp[1], c = tp[2];
+                    th.t = isect_triangle(pt.o, pt.d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), th.u, th.v);
+                }
+                const bool alive = segment_finish<STATS>(p, pt, th, stack, kTraceBlock, tl);
+                if (alive) {
+                    state = BEGIN;
+                } else {
+                    store_color(colors, item, pt.color);
+                    tl.paths++;
+                    state = IDLE;
+                }
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+}
+
 // RB_FLAG_FAST_BVH, stepped: the opt-in walk (FastWalk, rb_device_intersect.hpp) with the same
 // scheduling idea as k_trace_bvh.  Per-ray walk lengths differ a lot (a few dozen dependent node
 // fetches), so in the per-segment form (k_trace) a wavefront waits for its slowest lane with ~20 %
@@ -924,6 +1172,18 @@ __global__ void k_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint3
     if (j < n) out[j] = ptris[slots[j]];
 }
 
+// Prepared triangles into the chunked walk's order, as three arrays of 16-byte pieces so that 16 lanes testing the 16
+// triangles of a chunk read 256 consecutive bytes per piece.
+__global__ void k_chunk_gather(const PrepTri* ptris, const uint32_t* pos_slot, const uint32_t* pos_rank, uint32_t n, float4* a,
+                               float4* b, float4* c) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const PrepTri t = ptris[pos_slot[j]];
+    a[j] = make_float4(t.v0[0], t.v0[1], t.v0[2], __uint_as_float(pos_rank[j]));
+    b[j] = make_float4(t.e1[0], t.e1[1], t.e1[2], 0.0f);
+    c[j] = make_float4(t.e2[0], t.e2[1], t.e2[2], 0.0f);
+}
+
 // Multi-GPU assembly on the root device: every rank's padded stripe buffer arrives
 // back to back in `gathered`; stripe s of the frame belongs to rank s % n, which stores its stripes in order.
 __global__ void __launch_bounds__(256) k_deinterleave(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
@@ -1106,27 +1366,28 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
         // which trace kernel: multi-node tree walked exactly (from LDS when the mesh fits next to the
         // stacks: one 1024-thread block per CU, measured faster than three 256-thread blocks with a copy
         // each), the opt-in walk, the sphere tree, or the plain kernel (single-node tree, <= 64 spheres)
-        enum Variant { PLAIN, BVH, BVH_LDS, FAST, SPH };
+        enum Variant { PLAIN, BVH, BVH_LDS, FAST, SPH, CHUNK };
         const bool multi = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
         const size_t scene_lds = (size_t)p.u.bvh_node_count * 48u + (size_t)p.index_len * 48u;
         Variant v = PLAIN;
-        if (multi && p.fast_nodes != nullptr) v = FAST;
+        if (multi && p.chunk_nodes != nullptr) v = CHUNK;
+        else if (multi && p.fast_nodes != nullptr) v = FAST;
         else if (multi) {
             int dev = 0;
             (void)hipGetDevice(&dev);
             v = (p.lds_mode != 1u && lds * 4u + scene_lds <= max_dynamic_lds(dev)) ? BVH_LDS : BVH;
         }
         else if (p.sph_nodes != nullptr && !p.no_leaf_stepping) v = SPH;
-        static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph"};
+        static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph", "k_trace_chunk"};
         li.kernel_name = names[v];
         li.block = v == BVH_LDS ? 1024u : kTraceBlock;
-        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : lds;
+        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : v == CHUNK ? lds + (kTraceBlock / 64u) * kChunkWaveLds : lds;
         // residency (registers): k_trace 6 waves/SIMD, the stepped walks 4
         // (a launch of one or two samples per pixel -- the progressive iterator's -- leaves a wavefront of the full grid a
         // few hundred items: with half the grid each regenerates paths for longer and the tail is shorter: 1080p, 1 spp,
         // 0.72 instead of 0.80 ms per frame)
         const uint32_t dense = (items >= (uint64_t)device_cu_count_cached() * 8u * 4u * 1024u) ? 8u : 4u;
-        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : dense;
+        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : v == CHUNK ? (uint32_t)RB_CHUNK_WAVES : dense;
         li.grid = persistent_blocks(items, li.block, blocks_per_cu);
         if (li.grid == 0) return 0;
         // batch: the queue word sustains about 90 M atomics/s chip-wide, which 64-item reservations reach at 5-6 G
@@ -1158,6 +1419,10 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
             case SPH:
                 if (stats) hipLaunchKernelGGL(k_trace_sph<true>, grid, block, lds, stream, q);
                 else hipLaunchKernelGGL(k_trace_sph<false>, grid, block, lds, stream, q);
+                break;
+            case CHUNK:
+                if (stats) hipLaunchKernelGGL(k_trace_chunk<true>, grid, block, li.lds_bytes, stream, q);
+                else hipLaunchKernelGGL(k_trace_chunk<false>, grid, block, li.lds_bytes, stream, q);
                 break;
             case FAST:
                 if (stats) hipLaunchKernelGGL(k_trace_fast<true>, grid, block, lds, stream, q);
@@ -1218,6 +1483,15 @@ int launch_gather_tris(const PrepTri* ptris, const uint32_t* slots, uint32_t n, 
     if (n == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), dim3(256), 0, stream, ptris, slots, n, out);
+    return (int)hipGetLastError();
+}
+
+int launch_chunk_gather(const PrepTri* ptris, const uint32_t* pos_slot, const uint32_t* pos_rank, uint32_t n, float* a,
+                        float* b, float* c, void* stream_) {
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_chunk_gather, dim3((n + 255) / 256), dim3(256), 0, stream, ptris, pos_slot, pos_rank, n,
+                       reinterpret_cast<float4*>(a), reinterpret_cast<float4*>(b), reinterpret_cast<float4*>(c));
     return (int)hipGetLastError();
 }
 

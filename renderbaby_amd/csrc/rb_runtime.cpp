@@ -131,6 +131,12 @@ struct rb_engine {
     bool fast_ready = false;
     float fast_build_ms = 0.0f;
     const char* fast_builder = "";  // which builder produced the fast tree ("host-sah" / "device-ploc" / "device-lbvh")
+    DevBuf<rb::ChunkNode> chunk_nodes; // the chunked walk (rb_internal.hpp, ChunkTree)
+    DevBuf<float> chunk_a, chunk_b, chunk_c;
+    DevBuf<uint32_t> chunk_rank_slot;
+    uint32_t chunk_root = 0, chunk_depth = 0;
+    bool chunk_ready = false;
+    float chunk_build_ms = 0.0f;
     std::vector<rb_gpu_triangle> host_tris;  // kept while the library's own tree may be (re)built
     std::vector<uint32_t> host_indices;
     DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
@@ -388,6 +394,13 @@ bool wants_own_tree(const rb_engine* e, uint32_t n_tris) {
     return n_tris >= rb::kOwnTreeDefaultMinTriangles;
 }
 
+// the chunked walk (k_trace_chunk) for a mesh of n_tris triangles?
+bool wants_chunk_walk(const rb_engine* e, uint32_t n_tris) {
+    (void)n_tris;
+    if (e->opt.flags & (RB_FLAG_REFERENCE_WALK | RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) return false;
+    return (e->opt.flags & RB_FLAG_CHUNK_WALK) != 0u;
+}
+
 int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
     const Act act = field_action(idx, f, first);
     if (act == Act::None) return RB_OK;
@@ -538,9 +551,37 @@ int ensure_prepared(rb_engine* e) {
     if (rc) return fail(e, RB_ERR_DEVICE, "prep kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     e->prep_dirty = false;
     e->prep_tri_count = tri_count;
-    // ---- the library's own tree over the same triangles (default for multi-node meshes)
+    // ---- the chunked walk's tree: the caller's tree with the library's own levels below its leaves
+    e->chunk_ready = false;
     e->fast_ready = false;
-    if (wants_own_tree(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+    if (wants_chunk_walk(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+        rb::ChunkTree ct;
+        const auto t_begin = std::chrono::steady_clock::now();
+        const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
+        if (rb::chunk_tree_build(e->host_tris.data(), n_tris, e->host_indices.data(), static_cast<uint32_t>(e->host_indices.size()),
+                                 e->host_nodes.data(), static_cast<uint32_t>(e->host_nodes.size()), rb::kStackDepth, ct)) {
+            const size_t n = ct.pos_slot.size();
+            DevBuf<uint32_t> pos_slot, pos_rank;
+            rc = upload(e, e->chunk_nodes, ct.nodes.data(), ct.nodes.size(), nullptr, true);
+            if (!rc) rc = upload(e, e->chunk_rank_slot, ct.rank_slot.data(), ct.rank_slot.size(), nullptr, true);
+            if (!rc) rc = upload(e, pos_slot, ct.pos_slot.data(), n, nullptr, true);
+            if (!rc) rc = upload(e, pos_rank, ct.pos_rank.data(), n, nullptr, true);
+            if (rc) return rc;
+            HIP_TRY(e, e->chunk_a.resize(n * 4));
+            HIP_TRY(e, e->chunk_b.resize(n * 4));
+            HIP_TRY(e, e->chunk_c.resize(n * 4));
+            rc = rb::launch_chunk_gather(e->ptris.ptr, pos_slot.ptr, pos_rank.ptr, static_cast<uint32_t>(n), e->chunk_a.ptr, e->chunk_b.ptr,
+                                         e->chunk_c.ptr, e->stream);
+            if (rc) return fail(e, RB_ERR_DEVICE, "chunk gather launch failed");
+            HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ct`, pos_slot and pos_rank are locals
+            e->chunk_root = ct.root;
+            e->chunk_depth = ct.depth;
+            e->chunk_ready = true;
+            e->chunk_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        }
+    }
+    // ---- the library's own tree over the same triangles
+    if (!e->chunk_ready && wants_own_tree(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
         rb::FastTree ft;
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size());
@@ -662,7 +703,15 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     p.stripe_rows = e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows;
     p.local_rows = e->local_rows;
     p.colors = e->colors.ptr;
-    const bool use_fast = e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
+    const bool use_chunk = e->chunk_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
+    p.chunk_nodes = use_chunk ? e->chunk_nodes.ptr : nullptr;
+    p.chunk_a = e->chunk_a.ptr;
+    p.chunk_b = e->chunk_b.ptr;
+    p.chunk_c = e->chunk_c.ptr;
+    p.chunk_rank_slot = e->chunk_rank_slot.ptr;
+    p.chunk_root = e->chunk_root;
+    p.chunk_n = static_cast<uint32_t>(e->chunk_rank_slot.count);
+    const bool use_fast = !use_chunk && e->fast_ready && p.u.bvh_node_count == e->n_nodes && p.u.bvh_node_count > 1u;
     p.fast_nodes = use_fast ? e->fast_nodes.ptr : nullptr;
     p.gnodes = e->gnodes.ptr;
     p.gslots = e->gslots.ptr;
@@ -691,6 +740,7 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
     if (use_sph_bvh) p.stack_depth = std::max(p.stack_depth, e->sph_depth);
     if (use_fast) p.stack_depth = std::max(p.stack_depth, std::min(e->fast_depth, rb::kStackDepth));
+    if (use_chunk) p.stack_depth = std::max(use_sph_bvh ? e->sph_depth : 1u, e->chunk_depth + 1u);
     p.stack_overflow = e->stack_overflow.ptr;
     p.blocks_per_cu = e->opt._reserved[0];
     p.queue_batch = e->opt._reserved[2];

@@ -172,7 +172,7 @@ class Engine:
                  passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0,
                  no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False,
                  device_lbvh=False, reference_walk=False, host_bvh=False, devices=None, gather_peer_copy=False,
-                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0):
+                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0, chunk_walk=False):
         """``devices`` (list of HIP ordinals): one handle over several devices of this process
         (rb_create_multi): rows sharded in stripes, one RCCL gather per delivered frame."""
         self._lib = load()
@@ -190,7 +190,8 @@ class Engine:
             | (abi.FLAG_FAST_BVH if own_tree else 0) | (abi.FLAG_DEVICE_BVH if (device_bvh or device_lbvh) else 0) \
             | (abi.FLAG_DEVICE_LBVH if device_lbvh else 0) | (abi.FLAG_REFERENCE_WALK if reference_walk else 0) \
             | (abi.FLAG_HOST_BVH if host_bvh else 0) | (abi.FLAG_GATHER_PEER_COPY if gather_peer_copy else 0) \
-            | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0) | (abi.FLAG_SKIP_NEAR_DEGENERATE if skip_near_degenerate else 0)
+            | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0) | (abi.FLAG_SKIP_NEAR_DEGENERATE if skip_near_degenerate else 0) \
+            | (abi.FLAG_CHUNK_WALK if chunk_walk else 0)
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[2] = queue_batch   # items a wave reserves per queue atomic (0 = the launcher's choice)

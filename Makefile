@@ -7,7 +7,10 @@ CSRC     := renderbaby_amd/csrc
 OUT      := renderbaby_amd/librenderbaby_hip.so
 # Numerics contract: no FMA contraction, correctly rounded / and sqrt, no fast-math.
 NUMERICS := -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -Wall -Wno-unused-function
+# -fno-slp-vectorize: on gfx950 a packed f32 instruction (v_pk_mul_f32 ...) issues at half the rate of a plain one, so
+# SLP-packing adjacent scalar operations gains no throughput and costs the v_mov's that build the register pairs:
+# C2 26.4 -> 28.9 G segments/s, C1 21.8 -> 23.4, the mesh walks +4..9 % (profiles/r03_noslp.txt)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -fno-slp-vectorize -Wall -Wno-unused-function
 SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_build.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp $(CSRC)/rb_rccl.cpp
 HDRS     := $(CSRC)/rb_internal.hpp $(CSRC)/rb_device_common.hpp $(CSRC)/rb_device_math.hpp \
             $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp $(CSRC)/rb_rccl.hpp include/rb_abi.h

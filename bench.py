@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.algorithmic = null)")
     ap.add_argument("--skip-near-degenerate", action="store_true", help="RB_FLAG_SKIP_NEAR_DEGENERATE (the one unproved mode)")
-    ap.add_argument("--walk", default="", choices=["", "reference", "own", "own-host", "own-device"],
+    ap.add_argument("--walk", default="", choices=["", "reference", "own", "own-host", "own-device", "chunk"],
                     help="multi-node meshes: the reference walk or the library's own tree (default: the library's default)")
     ap.add_argument("--fast-bvh", action="store_true", help="same as --walk own-host")
     ap.add_argument("--device-bvh", action="store_true", help="same as --walk own-device")
@@ -76,7 +76,7 @@ def parse():
 
 def walk_kwargs(walk):
     return {"": {}, "reference": dict(reference_walk=True), "own": dict(own_tree=True), "own-host": dict(host_bvh=True),
-            "own-device": dict(device_bvh=True)}[walk]
+            "own-device": dict(device_bvh=True), "chunk": dict(chunk_walk=True)}[walk]
 
 
 def make_scene(name, spp):

@@ -329,10 +329,13 @@ static v3 scatter_metal(v3 ray_dir, v3 normal, float fuzz, uint32_t* seed) {
 /* ------------------------------------------------------------ trace_ray -- */
 static void ctx_init(ctx_t* c, const rbo_scene* s) {
     c->s = s;
-    /* gpu_wrapper.rs:475-495: counts from vector lengths */
+    /* gpu_wrapper.rs:475-495: counts from the vector lengths (Create / Update), or the caller's own value (Keep) */
     c->spheres_count = (uint32_t)s->n_spheres;
     c->node_count = (uint32_t)s->n_nodes;
-    c->tri_count = (uint32_t)s->n_tris;
+    c->tri_count = (uint32_t)s->n_tris;   /* shader.wgsl:336 compares triangle ids with this */
+    if ((s->counts_kept & 1u) && s->uniforms.spheres_count < c->spheres_count) c->spheres_count = s->uniforms.spheres_count;
+    if ((s->counts_kept & 2u) && s->uniforms.bvh_node_count < c->node_count) c->node_count = s->uniforms.bvh_node_count;
+    if ((s->counts_kept & 4u) && s->uniforms.bvh_triangle_count < c->tri_count) c->tri_count = s->uniforms.bvh_triangle_count;
     /* arrayLength(): an empty Vec still allocates one zero element (buffers.rs:232-240) */
     if (s->n_lights == 0) { c->lights = &k_phantom_light; c->light_len = 1u; }
     else { c->lights = s->lights; c->light_len = (uint32_t)s->n_lights; }

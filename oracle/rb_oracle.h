@@ -48,6 +48,12 @@ typedef struct rbo_scene {
     const float* uvs;              size_t n_uvs;
     const rb_texture* textures;    size_t n_textures;
     uint32_t samples_per_pass;     /* reference constant 1 (gpu_wrapper.rs:12); 0 => 1 */
+    uint32_t counts_kept;          /* update_uniforms' patch-up rule (gpu_wrapper.rs:475-495): a count is overwritten with
+                                      its vector's length when that field came as Create / Update, and the caller's value
+                                      in `uniforms` STAYS IN FORCE when the field was Keep.  Bit 0: spheres_count, bit 1:
+                                      bvh_node_count, bit 2: bvh_triangle_count were kept (0 = all three from the lengths).
+                                      A kept count beyond its array is clamped to the length (WGSL leaves such reads to
+                                      robust buffer access; the library clamps the same way). */
 } rbo_scene;
 
 typedef struct rbo_stats {

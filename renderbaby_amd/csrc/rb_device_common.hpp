@@ -28,6 +28,7 @@ DEV const RB_CONST T* cptr(const T* p) {
 // native vector types: HIP's float4/uint4 classes cannot be copy-constructed from address space 4
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef const RB_CONST v4f* cf4p;
 typedef const RB_CONST v4u* cu4p;
 typedef v4f nt_f4;  // nontemporal builtins want a native vector

@@ -262,13 +262,16 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 // Can a triangle whose normal lies in `cone` = {c cos(alpha), tan(alpha)} (every unit normal below is within alpha of
 // +-c) have |cos(d, n)| < c0?  |cos(d, n)| >= cos(alpha) (x - tan(alpha) sqrt(1 - x^2)) with x = |d . c|.  y = x cos(alpha)
 // is known to 6e-7, k2 - y^2 to 4e-6 k2; all zeros = no cone = always possible; tan(alpha) = -1 = nothing below = never.
-DEV bool cone_admits_grazing(f3 d, v4f cone) {
-    if (cone.w < 0.0f) return false;
+// cone_cos_bound: that lower bound of |cos(d, n)| over the cone (<= 0, or NaN, when it says nothing).
+DEV float cone_cos_bound(f3 d, v4f cone) {
     const float y = fabsf(__builtin_fmaf(d.z, cone.z, __builtin_fmaf(d.y, cone.y, d.x * cone.x)));
     const float k2 = __builtin_fmaf(cone.z, cone.z, __builtin_fmaf(cone.y, cone.y, cone.x * cone.x));
     const float root = 1.000001f * __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-y, y, k2), 0.0f) + 4e-6f * k2);
-    const float lb = __builtin_fmaf(-cone.w, root, y - 1e-6f);
-    return !(lb >= kFastGrazeCos);
+    return __builtin_fmaf(-cone.w, root, y - 1e-6f);
+}
+DEV bool cone_admits_grazing(f3 d, v4f cone) {
+    if (cone.w < 0.0f) return false;
+    return !(cone_cos_bound(d, cone) >= kFastGrazeCos);
 }
 constexpr float kFastKF = 27.0f * 5.9604645e-8f * 1.01f;
 constexpr float kFastKS = 20.0f * 5.9604645e-8f * 1.01f;

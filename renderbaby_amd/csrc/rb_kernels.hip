@@ -631,19 +631,28 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 // A lane whose stack runs empty is shaded (segment_finish) and starts its next segment or a new path while the others
 // keep walking, as in the other stepped kernels.
 #ifndef RB_CHUNK_WAVES
-#define RB_CHUNK_WAVES 4
+#define RB_CHUNK_WAVES 5   // 96 registers, 6 of them spilled: 1691 / 2598 / 2564 M segments/s on C3 / lamp / C5 against 1610 / 2418 / 2490 at 4
 #endif
 #ifndef RB_CHUNK_NODE_LANES
-#define RB_CHUNK_NODE_LANES 20   // keep stepping nodes while this many lanes are at one ...
+#define RB_CHUNK_NODE_LANES 32   // keep stepping nodes while this many lanes are at one ...
 #endif
 #ifndef RB_CHUNK_NODE_STEPS
-#define RB_CHUNK_NODE_STEPS 6    // ... but at most this many steps per outer iteration
+#define RB_CHUNK_NODE_STEPS 3    // ... but at most this many steps per outer iteration
 #endif
 #ifndef RB_CHUNK_LEAF_LANES
 #define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)
 #endif
+#ifndef RB_CHUNK_SP
+#define RB_CHUNK_SP 0
+#endif
+#ifndef RB_CHUNK_CONT
+#define RB_CHUNK_CONT 1
+#endif
+#ifndef RB_CHUNK_PIPE
+#define RB_CHUNK_PIPE 1          // request the next round's records before testing this round's
+#endif
 #ifndef RB_CHUNK_FINISH_LANES
-#define RB_CHUNK_FINISH_LANES 12 // shade once this many lanes have finished their walk (or nobody walks)
+#define RB_CHUNK_FINISH_LANES 32 // shade once this many lanes have finished their walk (or nobody walks)
 #endif
 constexpr float kChunkKF = 27.0f * 5.9604645e-8f * 1.01f;   // FastWalk's margin, with 4 u more for the slab arithmetic
 constexpr float kChunkKS = 24.0f * 5.9604645e-8f * 1.01f;   // done on the uninflated box (chunk_child)
@@ -662,12 +671,27 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float fx = fmaxf(t0.x, t1.x), fy = fmaxf(t0.y, t1.y), fz = fmaxf(t0.z, t1.z);
     const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
     if (exact && !(tmax >= fmaxf(tmin, 0.0f))) return false;   // the reference does not enter this node
-    // which bound of L^2 / |a^| this ray needs below the child: the determinant floor if it may graze a triangle there
+    // the bound of L^2 / |a^| this ray needs below the child
+#if RB_CHUNK_CONT
+    // |a| = N |cos(d, n)| >= N lb for every triangle below, lb = the cone's lower bound of |cos| for THIS ray: the bound
+    // (L^2 / N) / (0.95 lb) -- the stored one, made for |cos| >= c0, times c0 / lb -- up to the determinant floor,
+    // which holds whatever the angle (all zeros = no cone: lb <= 0; tan = -1 = nothing below: the floor of nothing)
+    const float lb = cone_cos_bound(d, cone);
+    const float cap = __uint_as_float(fac & 0xFFFF0000u);
+    const float fl = __uint_as_float(fac << 16) * (kFastGrazeCos * 1.00001f) * __builtin_amdgcn_rcpf(lb);
+    const float f = (lb > 1e-6f && fl < cap) ? fl : cap;   // NaN -> cap
+#else
+    // the determinant floor if it may graze a triangle there
     const float f = cone_admits_grazing(d, cone) ? __uint_as_float(fac & 0xFFFF0000u) : __uint_as_float(fac << 16);
+#endif
     // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
     const float mx = fmaxf(fabsf(a.x), fabsf(b.x)), my = fmaxf(fabsf(a.y), fabsf(b.y)), mz = fmaxf(fabsf(a.z), fabsf(b.z));
+#if RB_CHUNK_SP == 0
     const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz))) +
                       2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+#else   // the corner's distance by its largest component: within sqrt(3), three instructions instead of eight
+    const float sp_ = 1.7321f * fmaxf(fmaxf(mx, my), mz) + 2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+#endif
     const float mm = (f <= 1.5e5f) ? sp_ * __builtin_fmaf(kChunkKF, f, kChunkKS) : 1e30f;   // NaN -> 1e30
     const float ix = fabsf(inv.x), iy = fabsf(inv.y), iz = fabsf(inv.z);
     const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
@@ -689,6 +713,8 @@ DEV bool chunk_node_step(const KParams& p, uint32_t* stack, uint32_t stride, f3 
     const bool vl = lref != kChunkNone && chunk_child(l0, l1, __float_as_uint(r0.w), lc, exact, o, d, inv, best_t, kl);
     const bool vr = rref != kChunkNone && chunk_child(r0, r1, __float_as_uint(r1.w), rc, exact, o, d, inv, best_t, kr);
     if (vl && vr) {
+        // (the entry distance is not kept with the reference: dropping put-aside subtrees at the pop when a nearer hit
+        // has turned up meanwhile was measured -- 8-byte stack entries -- and removes 0.3 % of the box tests)
         const bool left_first = !(kr < kl);
         stack[sp * stride] = left_first ? rref : lref;
         sp++;
@@ -734,6 +760,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
     f3 inv = mk(0, 0, 0);
     unsigned long long key = kChunkNoHit;
     int sp = 0;
+#ifdef RB_CHUNK_PROFILE  // -DRB_CHUNK_PROFILE=1|2: pass occupancy instead of the work counters (tools/chunk_probe.py profile)
+    unsigned long long prof[5] = {0, 0, 0, 0, 0};
+#endif
 
     for (;;) {
         // ---- (1) hand items to idle lanes
@@ -771,10 +800,14 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         }
 
         // ---- (3) tree: a few node steps while enough lanes are at a node
+#pragma unroll 1
         for (int it = 0; it < RB_CHUNK_NODE_STEPS; ++it) {
             const bool at_node = state == TRAV && (cur & kChunkLeaf) == 0u;
             const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
             if (n == 0u || (it > 0 && n < (uint32_t)RB_CHUNK_NODE_LANES)) break;
+#if RB_CHUNK_PROFILE == 1
+            prof[0]++; prof[1] += n;
+#endif
             if (at_node && !chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl))
                 state = FINISH;
         }
@@ -796,23 +829,52 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const cf4p ca = (cf4p)p.chunk_a, cb = (cf4p)p.chunk_b, cc = (cf4p)p.chunk_c;
-                for (uint32_t g0 = 0; g0 < n_units; g0 += 4u) {
+                // one round = four pairs; the next round's ray records and triangle pieces are requested before
+                // this round's are tested
+                struct Round {
+                    v4f r0, r1, a, b, c;
+                    uint32_t rl;
+                    bool valid;
+                };
+                auto fetch = [&](uint32_t g0) {
+                    Round r;
                     const uint32_t g = g0 + (lane >> 4);
                     const bool ok = g < n_units;
-                    const uint32_t rl = units[ok ? g : 0u];
-                    const v4f r0 = rayrec[rl * 2u], r1 = rayrec[rl * 2u + 1u];
-                    const uint32_t ref = __float_as_uint(r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
+                    r.rl = units[ok ? g : 0u];
+                    r.r0 = rayrec[r.rl * 2u];
+                    r.r1 = rayrec[r.rl * 2u + 1u];
+                    const uint32_t ref = __float_as_uint(r.r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
                     const uint32_t j = lane & 15u;
-                    const bool valid = ok && j < cnt;
+                    r.valid = ok && j < cnt;
                     const uint32_t pos = first + (j < cnt ? j : 0u);
-                    const v4f a = ca[pos], b = cb[pos], c = cc[pos];
-                    if constexpr (STATS) tl.tris += valid ? 1u : 0u;
+                    r.a = ca[pos];
+                    r.b = cb[pos];
+                    r.c = cc[pos];
+                    return r;
+                };
+#if RB_CHUNK_PROFILE == 1
+                prof[2] += (n_units + 3u) / 4u; prof[3] += n_units;
+#elif RB_CHUNK_PROFILE == 2
+                prof[2]++;
+#endif
+#if RB_CHUNK_PIPE
+                Round nx = fetch(0u);
+#endif
+#pragma unroll 1
+                for (uint32_t g0 = 0; g0 < n_units; g0 += 4u) {
+#if RB_CHUNK_PIPE
+                    const Round r = nx;
+                    if (g0 + 4u < n_units) nx = fetch(g0 + 4u);
+#else
+                    const Round r = fetch(g0);
+#endif
+                    if constexpr (STATS) tl.tris += r.valid ? 1u : 0u;
                     float u, v;
-                    const float t = isect_triangle(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(a.x, a.y, a.z), mk(b.x, b.y, b.z),
-                                                   mk(c.x, c.y, c.z), u, v);
-                    if (valid && t > 0.001f) {
-                        const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(a.w);
-                        __hip_atomic_fetch_min(&best[rl], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const float t = isect_triangle(mk(r.r0.x, r.r0.y, r.r0.z), mk(r.r1.x, r.r1.y, r.r1.z), mk(r.a.x, r.a.y, r.a.z),
+                                                   mk(r.b.x, r.b.y, r.b.z), mk(r.c.x, r.c.y, r.c.z), u, v);
+                    if (r.valid && t > 0.001f) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(r.a.w);
+                        __hip_atomic_fetch_min(&best[r.rl], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if constexpr (STATS) tl.mesh_hits++;
                     }
                 }
@@ -834,6 +896,13 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         {
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(state == FINISH));
             const uint32_t n_trav = (uint32_t)__popcll(__ballot(state == TRAV));
+#if RB_CHUNK_PROFILE == 1
+            if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u)) prof[4]++;
+#elif RB_CHUNK_PROFILE == 2
+            prof[0]++;
+            if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u)) { prof[1] += n_fin; prof[4]++; }
+            prof[3] += n_trav;
+#endif
             if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u) && state == FINISH) {
                 TriHit th;
                 th.hit = key != kChunkNoHit;
@@ -860,6 +929,11 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         }
     }
     flush_tally<STATS>(tl, p.counters);
+#ifdef RB_CHUNK_PROFILE
+    // 1: node passes, lanes in them, leaf rounds, pairs in them, finish passes; 2: outer iterations, lanes shaded, leaf
+    // phases, walking lanes summed over the iterations, finish passes -> the five STATS counter slots
+    if (lane == 0u) for (int i = 0; i < 5; i++) atomicAdd(&p.counters[2 + i], prof[i]);
+#endif
 }
 
 // RB_FLAG_FAST_BVH, stepped: the opt-in walk (FastWalk, rb_device_intersect.hpp) with the same

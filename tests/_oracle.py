@@ -23,7 +23,7 @@ class Scene(C.Structure):
                 ("tris", C.c_void_p), ("n_tris", C.c_size_t),
                 ("uvs", C.c_void_p), ("n_uvs", C.c_size_t),
                 ("textures", C.c_void_p), ("n_textures", C.c_size_t),
-                ("samples_per_pass", C.c_uint32)]
+                ("samples_per_pass", C.c_uint32), ("counts_kept", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -96,7 +96,7 @@ def _f3(v):
 class OracleScene:
     """Keeps the numpy arrays alive and exposes the C struct."""
 
-    def __init__(self, scene, samples_per_pass=1):
+    def __init__(self, scene, samples_per_pass=1, counts_kept=0):
         self.scene = scene
         self._keep = []
         s = Scene()
@@ -124,6 +124,7 @@ class OracleScene:
         s.textures = C.cast(arr, C.c_void_p).value if texs else None
         s.n_textures = len(texs)
         s.samples_per_pass = samples_per_pass
+        s.counts_kept = counts_kept
         self.c = s
 
 
@@ -149,13 +150,17 @@ def cpu_share():
     return max(1, min(n, lib().rbo_max_threads()))
 
 
-def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0, samples_per_pass=1, cols=None):
+KEPT_SPHERES, KEPT_NODES, KEPT_TRIANGLES = 1, 2, 4   # rbo_scene.counts_kept
+
+
+def render(scene, first_pass=0, n_passes=None, accum=None, rows=None, threads=0, samples_per_pass=1, cols=None, counts_kept=0):
     """Returns (accum[h,w,4] f32, output[h,w] u32 packed shader order, rgba[h,w,4] mirrored, stats dict).
-    threads = 0: one per CPU this process may use (cpu_share)."""
+    threads = 0: one per CPU this process may use (cpu_share).  counts_kept: which of the three patched counts of
+    scene.uniforms stay in force instead of the array lengths (gpu_wrapper.rs:475-495, Change::Keep)."""
     L = lib()
     if threads <= 0:
         threads = cpu_share()
-    os_ = OracleScene(scene, samples_per_pass)
+    os_ = OracleScene(scene, samples_per_pass, counts_kept)
     w, h = scene.width, scene.height
     if n_passes is None:
         n_passes = scene.total_samples

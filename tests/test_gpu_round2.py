@@ -55,11 +55,11 @@ def test_refused_update_leaves_the_previous_scene_renderable():
     e.close()
 
 
-@pytest.mark.parametrize("kw", [dict(reference_walk=True), dict(host_bvh=True)], ids=["reference-walk", "own-tree"])
+@pytest.mark.parametrize("kw", [dict(reference_walk=True), dict(host_bvh=True), dict(chunk_walk=True)], ids=["reference-walk", "own-tree", "chunk-walk"])
 def test_keep_honours_the_callers_triangle_count(kw):
     # shader.wgsl:336 skips triangle ids >= uniforms.bvh_triangle_count, and gpu_wrapper.rs:489-495 leaves the
     # caller's count in force when the triangles are Keep: a uniforms-only update with a smaller count renders
-    # fewer triangles.  The oracle takes its count from the array length: the same scene with the array cut.
+    # fewer triangles.  The oracle applies the same patch-up rule (rbo_scene.counts_kept).
     s = scenes.mesh_scene(10, 10, 32, 20, 2, 3)
     n = len(s.bvh_triangles)
     rc = RenderConfig.from_scene(s)
@@ -70,10 +70,10 @@ def test_keep_honours_the_callers_triangle_count(kw):
         u = s.uniforms.copy()
         u["bvh_triangle_count"] = count
         got = e.render(RenderConfig(uniforms=Change.update(u))).pixels.copy()
-        k = min(count, n)
-        cut = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices,
-                           s.bvh_triangles[:k].copy(), s.uvs, s.textures)
-        assert np.array_equal(got, _oracle.render(cut)[2]), count
+        kept = scenes.Scene(u, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices, s.bvh_triangles, s.uvs, s.textures)
+        want = _oracle.render(kept, counts_kept=_oracle.KEPT_TRIANGLES)[2]
+        assert np.array_equal(got, want), count
+        assert (count >= n) == np.array_equal(want, full)   # the count really bites
     e.close()
 
 

@@ -71,9 +71,11 @@ def speed(which):
             kn = e.last_kernel_name()
             e.close()
             # work counters from an instrumented engine (one pass)
-            e = Engine.new(rc, stats=True, **kw)
-            e.update(rc); e.clear(); e.dispatch(0, 1); e.sync()
-            ws = e.stats(); e.close()
+            ws = {"segments": 1, "nodes_popped": 0, "tris_tested": 0}
+            if not os.environ.get("NOSTATS"):
+                e = Engine.new(rc, stats=True, **kw)
+                e.update(rc); e.clear(); e.dispatch(0, 1); e.sync()
+                ws = e.stats(); e.close()
             if ref is None:
                 ref = acc
             diff = int((ref.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
@@ -82,8 +84,27 @@ def speed(which):
                   f"differing pixels vs first {diff}  nodes/seg {ws['nodes_popped'] / seg:6.1f} tris/seg {ws['tris_tested'] / seg:6.1f}", flush=True)
 
 
+def prof(which):
+    """With a -DRB_CHUNK_PROFILE=1|2 build (RB_LIBRARY_PATH): the raw counter slots of one instrumented pass."""
+    from tests import _refscenes
+    mk = {"c3": lambda: scenes.mesh_c3().with_params(spp=4), "lamp": lambda: _refscenes.ref_lamp(spp=2),
+          "c5": lambda: scenes.mesh_c5().with_params(spp=1)}
+    for name in which:
+        s = mk[name]()
+        rc = RenderConfig.from_scene(s)
+        e = Engine.new(rc, stats=True, chunk_walk=True)
+        e.update(rc); e.clear(); e.dispatch(0, s.total_samples); e.sync()
+        st = e.stats(); e.close()
+        seg = st["segments"]
+        print(name, os.environ.get("RB_LIBRARY_PATH", ""), "segments", seg, "per segment:",
+              {k: round(st[k] / seg, 4) for k in ("nodes_popped", "tris_tested", "spheres_tested", "lights_tested", "mesh_hits")}, flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "parity"
     if mode == "parity":
         sys.exit(1 if parity() else 0)
+    if mode == "prof":
+        prof(sys.argv[2:] or ["c3", "lamp", "c5"])
+        sys.exit(0)
     speed(sys.argv[2:] or ["c3", "lamp", "c5"])

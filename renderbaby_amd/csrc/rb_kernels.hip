@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #define RB_CHUNK_NODE_LANES 32   // keep stepping nodes while this many lanes are at one ...
 #endif
 #ifndef RB_CHUNK_NODE_STEPS
-#define RB_CHUNK_NODE_STEPS 3    // ... but at most this many steps per outer iteration
+#define RB_CHUNK_NODE_STEPS 5    // ... but at most this many steps per outer iteration
 #endif
 #ifndef RB_CHUNK_LEAF_LANES
 #define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)
@@ -648,6 +648,9 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #ifndef RB_CHUNK_CONT
 #define RB_CHUNK_CONT 1
 #endif
+#ifndef RB_CHUNK_DEFER
+#define RB_CHUNK_DEFER 1         // a lane that reaches a chunk puts it aside and walks on to its next one before it waits
+#endif
 #ifndef RB_CHUNK_PIPE
 #define RB_CHUNK_PIPE 1          // request the next round's records before testing this round's
 #endif
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #endif
 constexpr float kChunkKF = 27.0f * 5.9604645e-8f * 1.01f;   // FastWalk's margin, with 4 u more for the slab arithmetic
 constexpr float kChunkKS = 24.0f * 5.9604645e-8f * 1.01f;   // done on the uninflated box (chunk_child)
-constexpr uint32_t kChunkWaveLds = 64u * 32u + 64u * 8u + 64u * 4u;   // per wave: ray records, best keys, unit table
+constexpr uint32_t kChunkWaveLds = 64u * 32u + 64u * 8u + 128u * 4u;  // per wave: ray records, best keys, unit table
 constexpr unsigned long long kChunkNoHit = 0x60AD78EC00000000ull;     // (bits of 1e20f) << 32: shader.wgsl:283-290
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
@@ -749,17 +752,34 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
     unsigned char* const wl = reinterpret_cast<unsigned char*>(s_stack + p.stack_depth * kTraceBlock) + (tid >> 6) * kChunkWaveLds;
     lds_v4f* const rayrec = (lds_v4f*)wl;                    // [64][2]: {o, chunk reference}, {d, -}
     lds_u64* const best = (lds_u64*)(wl + 64u * 32u);        // [64]: (t bits) << 32 | rank
-    lds_u32* const units = (lds_u32*)(wl + 64u * 40u);       // [64]: ray lane of every pooled (ray, chunk) pair
+    lds_u32* const units = (lds_u32*)(wl + 64u * 40u);       // [128]: ray lane (| 64: its second chunk) of every pooled (ray, chunk) pair
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0, cur = 0;
+    [[maybe_unused]] uint32_t pend = kChunkNone;   // RB_CHUNK_DEFER: the chunk this lane has put aside (cur == kChunkNone: nothing else left to walk)
     ItemQueue iq(p.queue_batch, total_items);
     Path pt;
     pt.depth = 0;
     f3 inv = mk(0, 0, 0);
     unsigned long long key = kChunkNoHit;
     int sp = 0;
+    // RB_CHUNK_DEFER: a lane whose walk arrives at a chunk while it holds none aside keeps the chunk for the next leaf
+    // phase and goes on with the subtree it had put aside, so it takes part in twice as many node passes between two
+    // waits (the best t it culls with is then one chunk behind: never wrong, rarely wasteful -- few chunk visits hit)
+    auto set_aside = [&]() {
+#if RB_CHUNK_DEFER
+        if (state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) != 0u && pend == kChunkNone) {
+            pend = cur;
+            if (sp == 0) {
+                cur = kChunkNone;
+            } else {
+                sp--;
+                cur = stack[sp * kTraceBlock];
+            }
+        }
+#endif
+    };
 #ifdef RB_CHUNK_PROFILE  // -DRB_CHUNK_PROFILE=1|2: pass occupancy instead of the work counters (tools/chunk_probe.py profile)
     unsigned long long prof[5] = {0, 0, 0, 0, 0};
 #endif
@@ -802,26 +822,41 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         // ---- (3) tree: a few node steps while enough lanes are at a node
 #pragma unroll 1
         for (int it = 0; it < RB_CHUNK_NODE_STEPS; ++it) {
-            const bool at_node = state == TRAV && (cur & kChunkLeaf) == 0u;
+            const bool at_node = state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) == 0u;
             const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
             if (n == 0u || (it > 0 && n < (uint32_t)RB_CHUNK_NODE_LANES)) break;
 #if RB_CHUNK_PROFILE == 1
             prof[0]++; prof[1] += n;
 #endif
-            if (at_node && !chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl))
-                state = FINISH;
+            if (at_node) {
+                if (!chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl)) {
+#if RB_CHUNK_DEFER
+                    if (pend != kChunkNone) cur = kChunkNone;   // nothing left to walk, one chunk still to be tested
+                    else
+#endif
+                    state = FINISH;
+                }
+                set_aside();
+            }
         }
 
-        // ---- (4) leaves: pool the (ray, chunk) pairs of the lanes that wait at a chunk, 16 lanes per pair
+        // ---- (4) leaves: pool the (ray, chunk) pairs of the lanes that hold a chunk, 16 lanes per pair
         {
-            const bool lf = state == TRAV && (cur & kChunkLeaf) != 0u;
-            const unsigned long long m = __ballot(lf);
-            const uint32_t n_units = (uint32_t)__popcll(m);
-            const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && !lf));
+            const bool lf = state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) != 0u;   // waits at a chunk
+#if RB_CHUNK_DEFER
+            const bool lp = state == TRAV && pend != kChunkNone;                              // holds one aside
+#else
+            const bool lp = false;
+#endif
+            const unsigned long long m = __ballot(lf), mp = __ballot(lp);
+            const uint32_t n_pend = (uint32_t)__popcll(mp), n_units = n_pend + (uint32_t)__popcll(m);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && cur != kChunkNone && !lf));
             if (n_units != 0u && (n_units >= (uint32_t)RB_CHUNK_LEAF_LANES || n_node == 0u)) {
-                if (lf) {
-                    units[(uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lane;
-                    const v4f r0 = {pt.o.x, pt.o.y, pt.o.z, __uint_as_float(cur)}, r1 = {pt.d.x, pt.d.y, pt.d.z, 0.0f};
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (lp) units[(uint32_t)__popcll(mp & below)] = lane;
+                if (lf) units[n_pend + (uint32_t)__popcll(m & below)] = lane | 64u;
+                if (lf || lp) {
+                    const v4f r0 = {pt.o.x, pt.o.y, pt.o.z, __uint_as_float(pend)}, r1 = {pt.d.x, pt.d.y, pt.d.z, __uint_as_float(cur)};
                     rayrec[lane * 2u] = r0;
                     rayrec[lane * 2u + 1u] = r1;
                     best[lane] = key;
@@ -840,10 +875,11 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                     Round r;
                     const uint32_t g = g0 + (lane >> 4);
                     const bool ok = g < n_units;
-                    r.rl = units[ok ? g : 0u];
+                    const uint32_t e = units[ok ? g : 0u];
+                    r.rl = e & 63u;
                     r.r0 = rayrec[r.rl * 2u];
                     r.r1 = rayrec[r.rl * 2u + 1u];
-                    const uint32_t ref = __float_as_uint(r.r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
+                    const uint32_t ref = __float_as_uint((e & 64u) ? r.r1.w : r.r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
                     const uint32_t j = lane & 15u;
                     r.valid = ok && j < cnt;
                     const uint32_t pos = first + (j < cnt ? j : 0u);
@@ -880,14 +916,18 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (lf) {
+                if (lf || lp) {
                     key = best[lane];
-                    if (sp == 0) {
-                        state = FINISH;
-                    } else {
-                        sp--;
-                        cur = stack[sp * kTraceBlock];
+                    pend = kChunkNone;
+                    if (lf || cur == kChunkNone) {   // the chunk the lane stood at is done, or there was nothing left to walk
+                        if (sp == 0) {
+                            state = FINISH;
+                        } else {
+                            sp--;
+                            cur = stack[sp * kTraceBlock];
+                        }
                     }
+                    set_aside();
                 }
             }
         }

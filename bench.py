@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
     ap.add_argument("--color-budget-mib", type=int, default=0, help="colour-buffer budget of the stream kernels (0 = library default)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last assembled RGBA8 frame to this .npy")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end leg (one more full render on a fresh engine)")
     a = ap.parse_args()
     if a.fast_bvh:
         a.walk = "own-host"
@@ -169,6 +170,60 @@ def measured_copy_bandwidth(device):
     return 2.0 * n * reps / dt / 1e9
 
 
+def measured_l1_ceiling(device):
+    """Lane accesses per second of divergent 16-byte gathers from an L2-resident table (rb_measure_l1_gather): the
+    ceiling of the L1 / texture-address path on this box.  TCP_TOTAL_CACHE_ACCESSES counts one access per lane of such
+    a load (calibrated with rocprofv3 on the same kernel: profiles/r03_l1_ceiling.txt), so a kernel's counter rate
+    compares with it directly."""
+    import ctypes as C
+    from renderbaby_amd import _lib
+    v = C.c_double()
+    if _lib.load().rb_measure_l1_gather(device, 0, C.byref(v)) != 0:
+        return None
+    return v.value
+
+
+def end_to_end(scene, wkw, kernel, device):
+    """The reference harness interval (src/control_plane/modes/benchmark.rs:32-46 -> scene_engine_adapter.rs:505-512:
+    flatten + BVH build + buffer creation + uploads + all passes + read-back) on a fresh engine, piece by piece (wall
+    clock, each piece synchronised): what the kernel figure leaves out."""
+    import ctypes as C
+    import numpy as np
+    from renderbaby_amd import Engine, RenderConfig, _lib, abi
+    rc = RenderConfig.from_scene(scene)
+    out = {}
+    n = len(scene.bvh_triangles)
+    tris = np.ascontiguousarray(scene.bvh_triangles, dtype=abi.GPU_TRIANGLE)
+    nodes, idx, n_nodes = np.zeros(2 * n + 1, dtype=abi.BVH_NODE), np.zeros(max(n, 1), dtype=np.uint32), C.c_size_t(0)
+    t = time.perf_counter()
+    if n:   # the caller's side: the reference's median-split tree (bvh.rs:87-150), one build
+        _lib.load().rb_bvh_build(tris.ctypes.data, n, nodes.ctypes.data, len(nodes), C.byref(n_nodes), idx.ctypes.data)
+    out["reference_tree_build_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    eng = Engine.new(rc, device=device, kernel=kernel, **wkw)
+    eng.update(rc)
+    eng.sync()
+    out["upload_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    eng.dispatch(0, 0)                       # prepared triangles + the library's own levels of the tree, nothing traced
+    eng.sync()
+    out["tree_build_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    eng.clear()
+    eng.dispatch(0, scene.total_samples)
+    eng.sync()
+    out["render_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    frame = eng.read_rgba()
+    out["readback_ms"] = (time.perf_counter() - t) * 1e3
+    eng.close()
+    out["total_ms"] = sum(out[k] for k in ("reference_tree_build_ms", "upload_ms", "tree_build_ms", "render_ms", "readback_ms"))
+    out["note"] = ("wall clock on a fresh engine; reference_tree_build = the caller's median-split tree over the scene's triangles "
+                   "(the reference rebuilds it per render, scene_engine_adapter.rs:435-440), tree_build = prepared triangles + the "
+                   "library's own levels; benchmark.rs:43-45 times the sum")
+    return out, frame
+
+
 def load_pmc(key, kernel_name, fingerprint):
     """Per-segment constants of the dominant kernel from the rocprofv3 PMC profile of this build
     (tools/profile_bench.sh -> profiles/<tag>_<key>_pmc.json).  -> (dict | None, note)."""
@@ -260,6 +315,18 @@ def main():
     seg_per_step = st["segments"] // max(a.steps, 1)
     paths_per_step = st["paths"] // max(a.steps, 1)
 
+    # ---- what the exchange looked like from inside (rb_comm_info): the communicator as RCCL itself reports it, this
+    # rank's share of the last gather, this rank's trace-kernel time per step
+    ci = r.engine.comm_info() if r.library_gather else {"rccl_ranks": 0, "rccl_rank": 0, "gather_ms": 0.0}
+    mine = torch.tensor([float(ci["rccl_ranks"]), float(ci["rccl_rank"]), float(ci["gather_ms"]),
+                         st["trace_ms"] / max(a.steps, 1)], dtype=torch.float64, device=red_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
+
     tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([float(seg_per_step), float(paths_per_step)], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -298,12 +365,22 @@ def main():
                 l2 = {"achieved": c["l2_bytes"] * seg_rate / 1e9, "peak": L2_PEAK_GBPS, "unit": "GB/s",
                       "l1_accesses_per_segment": c.get("tcp_accesses")}
                 l2["frac"] = l2["achieved"] / l2["peak"]
+            # the L1 / texture-address path: the kernel's L1 access rate against the rate this box sustains on divergent
+            # 16-byte gathers (one access per lane per load)
+            l1 = None
+            l1_peak = measured_l1_ceiling(local_rank)
+            if c.get("tcp_accesses") and l1_peak:
+                l1 = {"achieved": c["tcp_accesses"] * seg_rate / 1e9, "peak": l1_peak / 1e9, "unit": "G accesses/s",
+                      "accesses_per_segment": c["tcp_accesses"],
+                      "accesses_per_triangle_test": (c["tcp_accesses"] / (stats["tris_tested"] / max(stats["segments"], 1)))
+                      if (stats and stats.get("tris_tested")) else None}
+                l1["frac"] = l1["achieved"] / l1["peak"]
             # the binding ceiling = the largest of the fractions
-            cands = [("valu", valu)] + ([("l2", l2)] if l2 else []) + [("hbm", hbm)]
+            cands = [("valu", valu)] + ([("l1", l1)] if l1 else []) + ([("l2", l2)] if l2 else []) + [("hbm", hbm)]
             bound, top = max(cands, key=lambda kv: kv[1]["frac"])
             roof.update({"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                          "frac": top["frac"], "traffic": c["hbm_bytes"] * seg_per_step / launches,
-                         "valu": valu, "hbm": hbm, "l2": l2, "pmc_profile": pmc["_path"]})
+                         "valu": valu, "l1": l1, "hbm": hbm, "l2": l2, "pmc_profile": pmc["_path"]})
         else:
             roof["note"] = pmc_note
         if stats is not None and k_ms > 0:
@@ -323,6 +400,28 @@ def main():
         cpu = None
         if a.cpu_seconds > 0 and world == 1:
             cpu = cpu_baseline(scene, a.cpu_seconds)
+        # ---- the frame itself: a checksum every N must reproduce (the sharded frame is the single-GPU frame by construction)
+        import zlib
+        import numpy as np
+        fr = None if frame is None else (frame if isinstance(frame, np.ndarray) else frame.cpu().numpy())
+        crc = None if fr is None else (zlib.crc32(np.ascontiguousarray(fr).tobytes()) & 0xFFFFFFFF)
+        expect = None
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", "frame_crc32.json")))
+            expect = table.get(f"{a.workload}:{scene.width}x{scene.height}:{spp}spp:depth{int(scene.uniforms['max_depth'][0])}")
+        except Exception:
+            pass
+        verify = {"frame_crc32": crc, "frame_crc32_single_gpu": expect,
+                  "frame_matches_single_gpu": (None if (crc is None or expect is None) else bool(crc == expect))}
+        if world > 1:
+            verify.update({"rccl_ranks_reported": [int(x[0]) for x in per_rank], "rccl_rank_reported": [int(x[1]) for x in per_rank],
+                           "gather_ms_by_rank": [x[2] for x in per_rank], "trace_ms_per_step_by_rank": [x[3] for x in per_rank],
+                           "trace_ms_per_step_min": min(x[3] for x in per_rank), "trace_ms_per_step_max": max(x[3] for x in per_rank),
+                           "exchange": r.gather_note})
+        e2e = None
+        if world == 1 and not a.no_end_to_end:
+            e2e, e2e_frame = end_to_end(scene, wkw, a.kernel, local_rank)
+            e2e["frame_equals_timed_frame"] = bool(fr is not None and np.array_equal(e2e_frame, fr))
         out = {
             "metric": "Msamples/s (ray-segments/s)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -335,7 +434,7 @@ def main():
                        "stripe_rows": a.stripe_rows, "walk": a.walk or "library default",
                        "tree_builder": r.engine.fast_bvh_builder()[0],
                        "device": engine.device_name(local_rank)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "verify": verify,
             "kernel_ms_per_step_median": sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else None,
         }
         if cpu:

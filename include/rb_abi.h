@@ -233,25 +233,25 @@ enum {
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
     RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first) plus
                               a second pass over the caller's tree for hits reported from near-zero determinants, and accept
-                              a hit only if the reference's traversal would have tested it: proved to deliver the reference
-                              walk's frames.  Without this flag or RB_FLAG_REFERENCE_WALK the library
-                              chooses: its own tree from 393 216 triangles up, the reference walk below */
+                              a hit only if the reference's traversal would have tested it: argued and fuzzed to deliver the
+                              reference walk's frames.  Without a walk flag the library uses the
+                              chunked walk (RB_FLAG_CHUNK_WALK) */
     RB_FLAG_DEVICE_BVH = 8u, /* with RB_FLAG_FAST_BVH: build that tree on the GPU (Morton order + locally-ordered
                                 clustering) instead of on the host (binned SAH): milliseconds instead of ~0.5 s per
                                 million triangles, the same frames */
     RB_FLAG_DEVICE_LBVH = 16u, /* with RB_FLAG_DEVICE_BVH: plain LBVH instead of the clustering (ablation: faster
                                  build, slower walk) */
     RB_FLAG_REFERENCE_WALK = 32u, /* multi-node meshes: walk the caller's tree exactly as shader.wgsl:282-392 does
-                                     (128-triangle leaves, no culling) instead of the library's own tree; same frames */
+                                     (128-triangle leaves, fixed order, no culling); same frames, 2-5x slower */
     RB_FLAG_HOST_BVH = 64u, /* build the library's tree on the host (binned SAH) whatever the triangle count */
     RB_FLAG_GATHER_PEER_COPY = 128u, /* rb_create_multi: move the stripes with hipMemcpyPeerAsync instead of RCCL
                                         (hosts without librccl; several shards on one device in the tests) */
     RB_FLAG_NO_RUN_AHEAD = 256u, /* progressive iterator: do not start the next pass while a frame is read back */
-    RB_FLAG_CHUNK_WALK = 1024u, /* multi-node meshes: the chunked walk -- the caller's tree walked with the reference's own
-                                   slab arithmetic (nearer child first, subtrees culled on the best t by the margin that
-                                   bounds the reference's reported hits), the library's own levels below its leaves down
-                                   to 16-triangle chunks, which a wavefront tests cooperatively, one triangle per lane
-                                   (DESIGN.md section 4.2); same frames */
+    RB_FLAG_CHUNK_WALK = 1024u, /* multi-node meshes: the chunked walk, THE DEFAULT -- the caller's tree walked with the
+                                   reference's own slab arithmetic (nearer child first, subtrees culled on the best t by the
+                                   margin that bounds the reference's reported hits), the library's own levels below its
+                                   leaves down to 16-triangle chunks, which a wavefront tests cooperatively, one triangle
+                                   per lane; same frames.  The flag only makes the choice explicit */
     RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
                                            (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be
@@ -305,6 +305,12 @@ rb_engine* rb_create_multi(const rb_config* cfg, const rb_options* opt, const in
 #define RB_COMM_ID_BYTES 128
 int rb_comm_unique_id(uint8_t id_out[RB_COMM_ID_BYTES]);
 int rb_comm_init_rank(rb_engine* e, const uint8_t id[RB_COMM_ID_BYTES], uint32_t rank, uint32_t nranks);
+
+/* What the exchange of a sharded engine looks like from inside: the communicator's size and this handle's rank AS RCCL
+ * REPORTS THEM (ncclCommCount / ncclCommUserRank; 0 ranks when nothing goes through RCCL: a whole-frame engine, or the
+ * peer-copy transport), and the duration of this rank's share of the last gather (root: receives + de-interleave, on
+ * its exchange stream, HIP events).  Any pointer may be NULL.  No reference counterpart (one wgpu device). */
+int rb_comm_info(rb_engine* e, uint32_t* rccl_ranks, uint32_t* rccl_rank, float* last_gather_ms);
 
 /* drop(Engine) */
 void rb_destroy(rb_engine* e);
@@ -394,6 +400,9 @@ int rb_shard_layout(uint32_t height, uint32_t shard_rank, uint32_t shard_count, 
 uint32_t rb_shard_global_row(uint32_t shard_rank, uint32_t shard_count, uint32_t stripe_rows,
                              uint32_t local_row);
 
+/* Counters and times of every launch since the last rb_reset_stats.  While the progressive iterator is running they
+ * INCLUDE the pass group it has started ahead of the delivered frame (and one it later drops because the scene
+ * changed): the device counts what it traces. */
 int rb_get_stats(rb_engine* e, rb_stats* out);
 int rb_reset_stats(rb_engine* e);
 /* Duration of the most recent rb_dispatch launch group, HIP events on the
@@ -410,6 +419,10 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
 /* Test hook: evaluates the device's f32 /, sqrt, normalize, u32->f32, min/max and
  * dot on n input pairs (out8n: 8*n floats) so tests can check them against
  * IEEE-754 results computed on the host. */
+/* Measurement aid for the roofline record (bench.py): the rate at which this device serves divergent 16-byte gathers --
+ * every lane its own 128-byte line of a table of `table_bytes` (0 = 2 MiB, L2-resident) -- in lane accesses per second:
+ * the ceiling of the L1 / texture-address path that a lane-per-ray tree walk runs into. */
+int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_per_s);
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
 /* Test hook: checks the kernels' fast exact reciprocal against the compiler's correctly rounded
  * 1/b for all 2^23 significands (both signs) at one biased exponent; out16[0] = mismatch count. */

@@ -20,9 +20,9 @@ pub struct RbOptions {
     pub device: i32, pub shard_rank: u32, pub shard_count: u32, pub stripe_rows: u32,
     pub passes_per_launch: u32, pub kernel: u32, pub flags: u32, pub reserved: [u32; 5],
 }
-pub const RB_FLAG_FAST_BVH: u32 = 4;             // multi-node meshes: the library's own tree (proved exact, two passes)
+pub const RB_FLAG_FAST_BVH: u32 = 4;             // multi-node meshes: the library's own tree (argued and fuzzed exact, two passes)
 pub const RB_FLAG_DEVICE_BVH: u32 = 8;           // build that tree on the GPU
-pub const RB_FLAG_REFERENCE_WALK: u32 = 32;      // force the reference's walk (the default for multi-node meshes)
+pub const RB_FLAG_REFERENCE_WALK: u32 = 32;      // force the reference's walk (no flag = the chunked walk, RB_FLAG_CHUNK_WALK = 1024)
 pub const RB_FLAG_HOST_BVH: u32 = 64;            // build that tree on the host
 pub const RB_FLAG_GATHER_PEER_COPY: u32 = 128;   // rb_create_multi without RCCL
 pub const RB_FLAG_NO_RUN_AHEAD: u32 = 256;       // iterator: no pass started ahead of the read-back

@@ -1303,11 +1303,13 @@ __global__ void k_chunk_gather(const PrepTri* ptris, const uint32_t* pos_slot, c
 __global__ void __launch_bounds__(256) k_deinterleave(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
                                                        uint32_t width, uint32_t height, uint32_t padded_rows,
                                                        uint32_t stripe_rows, uint32_t n) {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
-    if (x >= width || y >= height) return;
-    const uint32_t s = y / stripe_rows, r = y - s * stripe_rows;
-    const uint32_t rank = s % n, local_row = (s / n) * stripe_rows + r;
-    frame[(size_t)y * width + x] = gathered[((size_t)rank * padded_rows + local_row) * width + x];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= width) return;
+    for (uint32_t y = blockIdx.y; y < height; y += gridDim.y) {   // (a grid's y extent stops at 65 535: taller frames loop)
+        const uint32_t s = y / stripe_rows, r = y - s * stripe_rows;
+        const uint32_t rank = s % n, local_row = (s / n) * stripe_rows + r;
+        frame[(size_t)y * width + x] = gathered[((size_t)rank * padded_rows + local_row) * width + x];
+    }
 }
 
 // Exhaustive check of rcp_newton against the compiler's correctly rounded 1/b: every one of the
@@ -1363,6 +1365,26 @@ __global__ void k_div_exhaustive(uint32_t b_begin, uint32_t ea, uint32_t eb, uin
             mismatch[2 + 2 * k] = __float_as_uint(b);
         }
     }
+}
+
+// Ceiling of the L1 / texture-address path, measured where the bench runs: every lane gathers 16 bytes from its own
+// pseudo-random 128-byte line of a table that fits in L2 (the access pattern of a lane-per-ray tree walk), eight
+// independent loads in flight per lane.  A wave instruction then costs 64 L1 accesses; accesses per second = the
+// number the mesh kernels' TCP_TOTAL_CACHE_ACCESSES rate is compared with (bench.py, roofline.l1).
+__global__ void __launch_bounds__(256) k_l1_gather(const float4* __restrict__ table, uint32_t lines_mask, uint32_t rounds, float4* sink) {
+    uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (uint32_t r = 0; r < rounds; r++) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            h = h * 747796405u + 2891336453u;
+            v[k] = table[(size_t)((h >> 9) & lines_mask) * 8u + ((h >> 3) & 7u)];   // line, 16-byte piece of it
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc.x += v[k].x, acc.y += v[k].y, acc.z += v[k].z, acc.w += v[k].w;
+    }
+    if (acc.x == 12345.678f) sink[0] = acc;   // never true for the zero-filled table: keeps the loads alive
 }
 
 // Exposes the device's /, sqrt, normalize and u32->f32 to the parity tests.
@@ -1613,8 +1635,8 @@ int launch_deinterleave(const uint32_t* gathered, uint32_t* frame, uint32_t widt
                         uint32_t stripe_rows, uint32_t shard_count, void* stream_) {
     if (width == 0 || height == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(k_deinterleave, dim3((width + 255u) / 256u, height), dim3(256), 0, stream, gathered, frame, width,
-                       height, padded_rows, stripe_rows, shard_count);
+    hipLaunchKernelGGL(k_deinterleave, dim3((width + 255u) / 256u, height < 65535u ? height : 65535u), dim3(256), 0, stream, gathered,
+                       frame, width, height, padded_rows, stripe_rows, shard_count);
     return (int)hipGetLastError();
 }
 
@@ -1636,6 +1658,35 @@ int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_rcp_exhaustive, dim3((1u << 23) / 256), dim3(256), 0, stream, expo, mismatch);
     return (int)hipGetLastError();
+}
+
+// -> lane accesses per second (0 on failure); table_bytes is rounded down to a power of two >= 64 KiB
+double measure_l1_gather(size_t table_bytes, uint32_t rounds) {
+    size_t lines = 512;
+    while (lines * 2 * 128 <= table_bytes) lines *= 2;
+    float4 *table = nullptr, *sink = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&table), lines * 128) != hipSuccess) return 0.0;
+    if (hipMalloc(reinterpret_cast<void**>(&sink), 16) != hipSuccess) { (void)hipFree(table); return 0.0; }
+    (void)hipMemset(table, 0, lines * 128);
+    hipEvent_t t0, t1;
+    (void)hipEventCreate(&t0);
+    (void)hipEventCreate(&t1);
+    const uint32_t blocks = device_cu_count_cached() * 8u;
+    double best = 0.0;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(t0, nullptr);
+        hipLaunchKernelGGL(k_l1_gather, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(lines - 1), rounds, sink);
+        (void)hipEventRecord(t1, nullptr);
+        if (hipEventSynchronize(t1) != hipSuccess) break;
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        if (ms > 0.0f) best = std::max(best, (double)blocks * 256.0 * rounds * 8.0 / (ms * 1e-3));
+    }
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    (void)hipFree(table);
+    (void)hipFree(sink);
+    return best;
 }
 
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream_) {

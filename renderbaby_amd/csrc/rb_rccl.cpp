@@ -22,6 +22,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
     int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -57,6 +59,8 @@ Rccl& rccl() {
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
         api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
         api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
@@ -113,7 +117,14 @@ int ensure_root_buffers(Gather& g, uint32_t n, uint32_t width, uint32_t height, 
     return 0;
 }
 
-// own stripes into slot `rank` of the gathered buffer, de-interleave, wait, copy the frame to the caller
+int ensure_timers(Gather& g, std::string& why) {   // on the device that is current
+    if (!g.t0) HIP_TRY_W(hipEventCreate(&g.t0));
+    if (!g.t1) HIP_TRY_W(hipEventCreate(&g.t1));
+    return 0;
+}
+
+// own stripes into slot `rank` of the gathered buffer, de-interleave, then the frame to the caller: a DMA on the same
+// stream into page-locked memory (rb_host_alloc, or memory the caller registered with HIP), else wait and copy
 int assemble_and_read(Gather& g, uint32_t n, uint32_t rank, const uint32_t* own, uint32_t width, uint32_t height,
                       uint32_t padded_rows, uint32_t stripe_rows, hipStream_t stream, uint8_t* rgba_out, std::string& why) {
     const size_t words = static_cast<size_t>(padded_rows) * width;
@@ -125,10 +136,51 @@ int assemble_and_read(Gather& g, uint32_t n, uint32_t rank, const uint32_t* own,
             return 1;
         }
     }
+    if (g.t1) HIP_TRY_W(hipEventRecord(g.t1, stream));
+    bool pinned = false;
+    if (rgba_out && g.frame_words) {
+        hipPointerAttribute_t attr{};
+        pinned = hipPointerGetAttributes(&attr, rgba_out) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();   // an unregistered pointer makes the query fail: the ordinary case
+        if (pinned) HIP_TRY_W(hipMemcpyAsync(rgba_out, g.frame, g.frame_words * 4, hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY_W(hipStreamSynchronize(stream));
-    if (rgba_out && g.frame_words) HIP_TRY_W(hipMemcpy(rgba_out, g.frame, g.frame_words * 4, hipMemcpyDeviceToHost));
+    if (rgba_out && g.frame_words && !pinned) HIP_TRY_W(hipMemcpy(rgba_out, g.frame, g.frame_words * 4, hipMemcpyDeviceToHost));
+    if (g.t0 && g.t1) (void)hipEventElapsedTime(&g.last_ms, g.t0, g.t1);
     return 0;
 }
+
+// A failed call between ncclGroupStart and ncclGroupEnd must not leave the thread's group open (every later
+// RCCL call of this thread would queue into it): remember the first failure, close the group, then report.
+struct GroupScope {
+    std::string first;
+    bool open = false;
+    void fail(const char* what, const std::string& msg) {
+        if (first.empty()) first = std::string(what) + " failed: " + msg;
+    }
+    void nccl(const char* what, int st) {
+        if (st != 0) fail(what, rccl().GetErrorString(st));
+    }
+    void hip(const char* what, hipError_t st) {
+        if (st != hipSuccess) fail(what, hipGetErrorString(st));
+    }
+    bool ok() const { return first.empty(); }
+    void start() {
+        const int st = rccl().GroupStart();
+        if (st != 0) fail("ncclGroupStart", rccl().GetErrorString(st));
+        else open = true;
+    }
+    int end(std::string& why) {   // 0, or 1 with `why`
+        if (open) {
+            open = false;
+            const int st = rccl().GroupEnd();
+            if (st != 0) fail("ncclGroupEnd", rccl().GetErrorString(st));
+        }
+        if (first.empty()) return 0;
+        why = first;
+        return 1;
+    }
+};
 
 }  // namespace
 
@@ -183,7 +235,15 @@ int gather_group(Gather& g, const std::vector<GatherSource>& parts, uint32_t wid
                  uint32_t stripe_rows, uint8_t* rgba_out, std::string& why) {
     const uint32_t n = static_cast<uint32_t>(parts.size());
     if (ensure_root_buffers(g, n, width, height, padded_rows, why)) return 1;
+    if (ensure_timers(g, why)) return 1;
     const size_t words = static_cast<size_t>(padded_rows) * width;
+    // every part's exchange stream starts behind the launches that produced its stripes
+    for (uint32_t r = 0; r < n; ++r) {
+        HIP_TRY_W(hipSetDevice(parts[r].device));
+        if (parts[r].ready) HIP_TRY_W(hipStreamWaitEvent(parts[r].stream, parts[r].ready, 0));
+    }
+    HIP_TRY_W(hipSetDevice(g.root_device));
+    HIP_TRY_W(hipEventRecord(g.t0, parts[0].stream));
     if (n > 1 && words) {
         if (g.peer_copy) {
             for (uint32_t r = 1; r < n; ++r) {
@@ -198,17 +258,18 @@ int gather_group(Gather& g, const std::vector<GatherSource>& parts, uint32_t wid
             HIP_TRY_W(hipSetDevice(g.root_device));
             for (uint32_t r = 1; r < n; ++r) HIP_TRY_W(hipStreamWaitEvent(parts[0].stream, g.arrived[r], 0));
         } else {
-            // one grouped call = the gather: every peer sends its stripes on the stream that rendered them, the
-            // root posts the matching receives on its own stream
-            NCCL_TRY(rccl().GroupStart());
-            for (uint32_t r = 1; r < n; ++r) {
-                HIP_TRY_W(hipSetDevice(parts[r].device));
-                NCCL_TRY(rccl().Send(parts[r].rgba, words * 4, kNcclUint8, 0, g.comms[r], parts[r].stream));
+            // one grouped call = the gather: every peer sends its stripes on its exchange stream, the root posts the
+            // matching receives on its own
+            GroupScope grp;
+            grp.start();
+            for (uint32_t r = 1; r < n && grp.ok(); ++r) {
+                grp.hip("hipSetDevice", hipSetDevice(parts[r].device));
+                if (grp.ok()) grp.nccl("ncclSend", rccl().Send(parts[r].rgba, words * 4, kNcclUint8, 0, g.comms[r], parts[r].stream));
             }
-            HIP_TRY_W(hipSetDevice(g.root_device));
-            for (uint32_t r = 1; r < n; ++r)
-                NCCL_TRY(rccl().Recv(g.gathered + r * words, words * 4, kNcclUint8, static_cast<int>(r), g.comms[0], parts[0].stream));
-            NCCL_TRY(rccl().GroupEnd());
+            if (grp.ok()) grp.hip("hipSetDevice", hipSetDevice(g.root_device));
+            for (uint32_t r = 1; r < n && grp.ok(); ++r)
+                grp.nccl("ncclRecv", rccl().Recv(g.gathered + r * words, words * 4, kNcclUint8, static_cast<int>(r), g.comms[0], parts[0].stream));
+            if (grp.end(why)) return 1;
         }
     }
     HIP_TRY_W(hipSetDevice(g.root_device));
@@ -216,21 +277,39 @@ int gather_group(Gather& g, const std::vector<GatherSource>& parts, uint32_t wid
 }
 
 int gather_process(Gather& g, const uint32_t* local_rgba, uint32_t width, uint32_t height, uint32_t padded_rows,
-                   uint32_t stripe_rows, hipStream_t stream, uint8_t* rgba_out, std::string& why) {
+                   uint32_t stripe_rows, hipStream_t stream, hipEvent_t ready, uint8_t* rgba_out, std::string& why) {
     const size_t words = static_cast<size_t>(padded_rows) * width;
+    if (ensure_timers(g, why)) return 1;
+    if (ready) HIP_TRY_W(hipStreamWaitEvent(stream, ready, 0));
+    HIP_TRY_W(hipEventRecord(g.t0, stream));
     if (g.rank != 0) {
         if (words) NCCL_TRY(rccl().Send(local_rgba, words * 4, kNcclUint8, 0, g.comms[0], stream));
+        HIP_TRY_W(hipEventRecord(g.t1, stream));
         HIP_TRY_W(hipStreamSynchronize(stream));
+        (void)hipEventElapsedTime(&g.last_ms, g.t0, g.t1);
         return 0;
     }
     if (ensure_root_buffers(g, g.nranks, width, height, padded_rows, why)) return 1;
-    if (words) {
-        NCCL_TRY(rccl().GroupStart());
-        for (uint32_t r = 1; r < g.nranks; ++r)
-            NCCL_TRY(rccl().Recv(g.gathered + r * words, words * 4, kNcclUint8, static_cast<int>(r), g.comms[0], stream));
-        NCCL_TRY(rccl().GroupEnd());
+    if (words && g.nranks > 1) {
+        GroupScope grp;
+        grp.start();
+        for (uint32_t r = 1; r < g.nranks && grp.ok(); ++r)
+            grp.nccl("ncclRecv", rccl().Recv(g.gathered + r * words, words * 4, kNcclUint8, static_cast<int>(r), g.comms[0], stream));
+        if (grp.end(why)) return 1;
     }
     return assemble_and_read(g, g.nranks, 0, local_rgba, width, height, padded_rows, stripe_rows, stream, rgba_out, why);
+}
+
+int gather_comm_info(const Gather& g, uint32_t* rccl_ranks, uint32_t* rccl_rank, std::string& why) {
+    if (rccl_ranks) *rccl_ranks = 0;
+    if (rccl_rank) *rccl_rank = 0;
+    if (g.comms.empty() || !g.comms[0]) return 0;
+    int n = 0, r = 0;
+    NCCL_TRY(rccl().CommCount(g.comms[0], &n));
+    NCCL_TRY(rccl().CommUserRank(g.comms[0], &r));
+    if (rccl_ranks) *rccl_ranks = static_cast<uint32_t>(n);
+    if (rccl_rank) *rccl_rank = static_cast<uint32_t>(r);
+    return 0;
 }
 
 void* gather_frame_ptr(const Gather& g) { return g.frame; }
@@ -248,7 +327,10 @@ void gather_destroy(Gather& g) {
             (void)hipEventDestroy(g.arrived[r]);
         }
     g.arrived.clear();
-    if (g.gathered || g.frame) (void)hipSetDevice(g.root_device);
+    if (g.gathered || g.frame || g.t0 || g.t1) (void)hipSetDevice(g.root_device);
+    if (g.t0) (void)hipEventDestroy(g.t0);
+    if (g.t1) (void)hipEventDestroy(g.t1);
+    g.t0 = g.t1 = nullptr;
     if (g.gathered) (void)hipFree(g.gathered);
     if (g.frame) (void)hipFree(g.frame);
     g.gathered = g.frame = nullptr;

@@ -15,7 +15,9 @@ namespace rb {
 
 struct GatherSource {
     int device;
-    hipStream_t stream;          // the stream the part's render was queued on
+    hipStream_t stream;          // the part's exchange stream (not the one it renders on: a pass that runs ahead of the
+                                 // delivered frame must not hold the gather back)
+    hipEvent_t ready;            // recorded behind the launches that produced `rgba`; the exchange stream waits for it
     const uint32_t* rgba;        // its padded stripe buffer (padded_rows * width)
 };
 
@@ -31,6 +33,8 @@ struct Gather {
     uint32_t* frame = nullptr;       // root: [height][width]
     size_t frame_words = 0;
     std::vector<hipEvent_t> arrived; // peer-copy transport: one per part
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // around this rank's share of the last gather (root: receives + de-interleave)
+    float last_ms = 0.0f;
 };
 
 // all return 0 or a non-zero status with `why` set
@@ -40,7 +44,10 @@ int gather_init_rank(Gather& g, int device, const uint8_t* id128, uint32_t rank,
 int gather_group(Gather& g, const std::vector<GatherSource>& parts, uint32_t width, uint32_t height, uint32_t padded_rows,
                  uint32_t stripe_rows, uint8_t* rgba_out, std::string& why);
 int gather_process(Gather& g, const uint32_t* local_rgba, uint32_t width, uint32_t height, uint32_t padded_rows,
-                   uint32_t stripe_rows, hipStream_t stream, uint8_t* rgba_out, std::string& why);
+                   uint32_t stripe_rows, hipStream_t stream, hipEvent_t ready, uint8_t* rgba_out, std::string& why);
+// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank of this rank's handle): 0 ranks when
+// the exchange does not go through RCCL (one device, or the peer-copy transport)
+int gather_comm_info(const Gather& g, uint32_t* rccl_ranks, uint32_t* rccl_rank, std::string& why);
 void* gather_frame_ptr(const Gather& g);
 void gather_destroy(Gather& g);
 

@@ -388,17 +388,19 @@ Act field_action(int idx, const rb_field& f, bool first) {
 // may the library's own tree be wanted for this engine's meshes?  (host copies of triangles / indices are kept then)
 bool may_want_own_tree(const rb_engine* e) { return !(e->opt.flags & RB_FLAG_REFERENCE_WALK); }
 // is it wanted for a mesh of n_tris triangles?
-bool wants_own_tree(const rb_engine* e, uint32_t n_tris) {
+bool wants_own_tree(const rb_engine* e, uint32_t n_tris) {   // (asked only when the chunked walk is not in use)
     if (e->opt.flags & RB_FLAG_REFERENCE_WALK) return false;
     if (e->opt.flags & (RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) return true;
     return n_tris >= rb::kOwnTreeDefaultMinTriangles;
 }
 
-// the chunked walk (k_trace_chunk) for a mesh of n_tris triangles?
-bool wants_chunk_walk(const rb_engine* e, uint32_t n_tris) {
-    (void)n_tris;
-    if (e->opt.flags & (RB_FLAG_REFERENCE_WALK | RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH)) return false;
-    return (e->opt.flags & RB_FLAG_CHUNK_WALK) != 0u;
+// The chunked walk (k_trace_chunk) is the walk of every multi-node mesh unless the caller names another one: it is
+// the fastest exact walk at every size measured (profiles/r03_walks.txt: 576 to 1 048 578 triangles).
+bool wants_chunk_walk(const rb_engine* e) {
+    const uint32_t kern = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
+    if (kern != RB_KERNEL_STREAM) return false;   // the one-pixel-per-lane dispatch shapes walk per segment
+    if (e->opt.flags & RB_FLAG_CHUNK_WALK) return true;
+    return !(e->opt.flags & (RB_FLAG_REFERENCE_WALK | RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_HOST_BVH));
 }
 
 int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
@@ -554,7 +556,7 @@ int ensure_prepared(rb_engine* e) {
     // ---- the chunked walk's tree: the caller's tree with the library's own levels below its leaves
     e->chunk_ready = false;
     e->fast_ready = false;
-    if (wants_chunk_walk(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+    if (wants_chunk_walk(e) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
         rb::ChunkTree ct;
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
@@ -743,7 +745,9 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     if (use_chunk) p.stack_depth = std::max(use_sph_bvh ? e->sph_depth : 1u, e->chunk_depth + 1u);
     p.stack_overflow = e->stack_overflow.ptr;
     p.blocks_per_cu = e->opt._reserved[0];
-    p.queue_batch = e->opt._reserved[2];
+    // the caller's reservation size: a multiple of 64 items, at most 4096 (the launcher's own range; beyond it the
+    // 32-bit queue arithmetic of the stream kernels could wrap and hand items out twice)
+    p.queue_batch = e->opt._reserved[2] ? std::min<uint32_t>(((std::min<uint32_t>(e->opt._reserved[2], 4096u) + 63u) / 64u) * 64u, 4096u) : 0u;
     p.no_leaf_stepping = e->opt._reserved[3];
     p.lds_mode = e->opt._reserved[4];
     return p;
@@ -978,7 +982,8 @@ int render_locked(rb_engine* e, uint8_t* rgba_out) {
     if (e->net.nranks > 1) {  // one process per device: the frame is assembled on rank 0
         std::string why;
         if (rb::gather_process(e->net, e->slot[e->cur].rgba.ptr, e->width, e->height, e->padded_rows,
-                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->stream, rgba_out, why))
+                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->copy_stream, e->slot[e->cur].done,
+                               rgba_out, why))
             return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
     } else {
         rc = read_rgba(e, rgba_out);
@@ -987,24 +992,22 @@ int render_locked(rb_engine* e, uint8_t* rgba_out) {
     return accumulate_timing(e);
 }
 
-// One delivered frame of the progressive iterator: passes [current_pass, +n).  The frame is taken from the
-// run-ahead slot when the previous call started exactly these passes there (and nothing has touched the
-// scene or the accumulation since); the next group is started on the other slot BEFORE this frame is
-// copied out, so compute and read-back overlap (frame_buffer.rs:164-221 pumps frames from a worker thread;
-// lib.rs:200-205 syncs, maps and mirrors per pass).
-int iter_next_locked(rb_engine* e, uint8_t* rgba_out) {
-    if (!(e->prh.current_pass < e->prh.total_passes))
-        return fail(e, RB_ERR_NO_MORE_FRAMES, "No more frames available");  // lib.rs:170-177
+// One step of the progressive iterator on one engine, without the delivery: passes [current_pass, +n) end up in
+// slot[cur].  They are taken from the run-ahead slot when the previous call started exactly these passes there (and
+// nothing has touched the scene or the accumulation since); then the next group is started on the other slot, so that
+// it computes while the caller's frame is exchanged and copied out (frame_buffer.rs:164-221 pumps frames from a worker
+// thread; lib.rs:200-205 syncs, maps and mirrors per pass).  The exchange and the read-back run on the engine's second
+// stream behind the slot's event, so a sharded engine -- one process per device, or a part of a multi-device handle --
+// runs ahead like a whole-frame one.
+int iter_advance(rb_engine* e, uint32_t per_frame) {
     int rc = require_ready(e);
     if (rc) return rc;
-    const bool multiproc = e->net.nranks > 1;
-    if (!rgba_out && !(multiproc && e->net.rank != 0)) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
     if (!e->iter_initialized) {  // lib.rs:181-192
         rc = clear_accum(e);
         if (rc) return rc;
         e->iter_initialized = true;
     }
-    const uint32_t per = std::max(e->iter_passes_per_frame, 1u);
+    const uint32_t per = std::max(per_frame, 1u);
     const uint32_t n = std::min(per, e->prh.total_passes - e->prh.current_pass);
     if (e->spec_valid && e->spec_first == e->prh.current_pass && e->spec_n == n) {
         e->cur = 1 - e->cur;   // commit the pass group that has been running since the previous call
@@ -1018,12 +1021,17 @@ int iter_next_locked(rb_engine* e, uint8_t* rgba_out) {
     rc = accumulate_timing(e);
     if (rc) return rc;
     // ---- run ahead: the next group on the other slot
-    const bool run_ahead = !multiproc && !(e->opt.flags & RB_FLAG_NO_RUN_AHEAD) && e->prh.current_pass < e->prh.total_passes;
-    if (run_ahead) {
+    if (!(e->opt.flags & RB_FLAG_NO_RUN_AHEAD) && e->prh.current_pass < e->prh.total_passes) {
         FrameSlot& o = e->slot[1 - e->cur];
         const size_t px = static_cast<size_t>(e->width) * e->padded_rows;
-        HIP_TRY(e, o.accum.resize(px * 4));
-        HIP_TRY(e, o.rgba.resize(px));
+        if (o.accum.count != px * 4 || o.rgba.count != px) {
+            HIP_TRY(e, o.accum.resize(px * 4));
+            HIP_TRY(e, o.rgba.resize(px));
+            // rows a sharded engine pads its stripes with are never written by a kernel: callers that read the
+            // slot must not see what the allocator left there
+            if (px) HIP_TRY(e, hipMemsetAsync(o.accum.ptr, 0, px * 16, e->stream));
+            if (px) HIP_TRY(e, hipMemsetAsync(o.rgba.ptr, 0, px * 4, e->stream));
+        }
         const uint32_t n2 = std::min(per, e->prh.total_passes - e->prh.current_pass);
         rc = dispatch(e, e->prh.current_pass, n2, e->cur, 1 - e->cur);
         if (rc) return rc;
@@ -1031,10 +1039,21 @@ int iter_next_locked(rb_engine* e, uint8_t* rgba_out) {
         e->spec_first = e->prh.current_pass;
         e->spec_n = n2;
     }
+    return RB_OK;
+}
+
+int iter_next_locked(rb_engine* e, uint8_t* rgba_out) {
+    if (!(e->prh.current_pass < e->prh.total_passes))
+        return fail(e, RB_ERR_NO_MORE_FRAMES, "No more frames available");  // lib.rs:170-177
+    const bool multiproc = e->net.nranks > 1;
+    if (!rgba_out && !(multiproc && e->net.rank != 0)) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
+    int rc = iter_advance(e, e->iter_passes_per_frame);
+    if (rc) return rc;
     if (multiproc) {
         std::string why;
         if (rb::gather_process(e->net, e->slot[e->cur].rgba.ptr, e->width, e->height, e->padded_rows,
-                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->stream, rgba_out, why))
+                               e->opt.stripe_rows ? e->opt.stripe_rows : rb::kDefaultStripeRows, e->copy_stream, e->slot[e->cur].done,
+                               rgba_out, why))
             return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
         return RB_OK;
     }
@@ -1137,15 +1156,18 @@ int group_update(rb_engine* g, const rb_config* cfg) {
 }
 
 // the one exchange step: every part's RGBA8 stripes to the root device, de-interleaved there, then read back
-int group_deliver(rb_engine* g, uint8_t* rgba_out) {
+int group_deliver(rb_engine* g, uint8_t* rgba_out, bool fold_timing) {
     std::vector<rb::GatherSource> src;
-    for (auto& p : g->parts) src.push_back(rb::GatherSource{p->device, p->stream, p->slot[p->cur].rgba.ptr});
+    for (auto& p : g->parts) src.push_back(rb::GatherSource{p->device, p->copy_stream, p->slot[p->cur].done, p->slot[p->cur].rgba.ptr});
     rb_engine* p0 = g->parts[0].get();
     const uint32_t sr = p0->opt.stripe_rows ? p0->opt.stripe_rows : rb::kDefaultStripeRows;
     std::string why;
     if (rb::gather_group(g->net, src, p0->width, p0->height, p0->padded_rows, sr, rgba_out, why))
         return fail(g, RB_ERR_DEVICE, "%s", why.c_str());
-    for (auto& p : g->parts) PART_TRY(g, p.get(), accumulate_timing(p.get()));
+    // (the iterator folds a group's timing when it commits it: waiting for the events here would wait for the pass
+    // that has just been started ahead)
+    if (fold_timing)
+        for (auto& p : g->parts) PART_TRY(g, p.get(), accumulate_timing(p.get()));
     return RB_OK;
 }
 
@@ -1153,26 +1175,16 @@ int group_render(rb_engine* g, uint8_t* rgba_out) {
     if (!rgba_out) return fail(g, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
     for (auto& p : g->parts) PART_TRY(g, p.get(), render_async(p.get()));  // all devices render concurrently
     g->prh = g->parts[0]->prh;
-    return group_deliver(g, rgba_out);
+    return group_deliver(g, rgba_out, true);
 }
 
 int group_iter_next(rb_engine* g, uint8_t* rgba_out) {
     rb_engine* p0 = g->parts[0].get();
     if (!(p0->prh.current_pass < p0->prh.total_passes)) return fail(g, RB_ERR_NO_MORE_FRAMES, "No more frames available");
     if (!rgba_out) return fail(g, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
-    for (auto& pp : g->parts) {
-        rb_engine* p = pp.get();
-        PART_TRY(g, p, require_ready(p));
-        if (!p->iter_initialized) {
-            PART_TRY(g, p, clear_accum(p));
-            p->iter_initialized = true;
-        }
-        const uint32_t n = std::min(std::max(g->iter_passes_per_frame, 1u), p->prh.total_passes - p->prh.current_pass);
-        PART_TRY(g, p, dispatch(p, p->prh.current_pass, n, p->cur, p->cur));
-        p->prh.current_pass += n;
-    }
+    for (auto& pp : g->parts) PART_TRY(g, pp.get(), iter_advance(pp.get(), g->iter_passes_per_frame));   // every part runs ahead
     g->prh = p0->prh;
-    return group_deliver(g, rgba_out);
+    return group_deliver(g, rgba_out, false);
 }
 
 }  // namespace
@@ -1242,6 +1254,15 @@ int rb_comm_init_rank(rb_engine* e, const uint8_t id[RB_COMM_ID_BYTES], uint32_t
     set_device(e);
     std::string why;
     if (rb::gather_init_rank(e->net, e->device, id, rank, nranks, why)) return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
+    return RB_OK;
+}
+
+int rb_comm_info(rb_engine* e, uint32_t* rccl_ranks, uint32_t* rccl_rank, float* last_gather_ms) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    std::string why;
+    if (rb::gather_comm_info(e->net, rccl_ranks, rccl_rank, why)) return fail(e, RB_ERR_DEVICE, "%s", why.c_str());
+    if (last_gather_ms) *last_gather_ms = e->net.last_ms;
     return RB_OK;
 }
 
@@ -1428,7 +1449,7 @@ int rb_read_rgba(rb_engine* e, uint8_t* rgba_out) {
     std::lock_guard<std::mutex> lock(e->mu);
     if (is_group(e)) {
         if (!rgba_out) return fail(e, RB_ERR_NULL_ARGUMENT, "rgba_out is NULL");
-        return group_deliver(e, rgba_out);
+        return group_deliver(e, rgba_out, false);
     }
     set_device(e);
     int rc = require_ready(e);
@@ -1699,6 +1720,13 @@ int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uin
 }
 
 // Debug hook for tests/test_gpu_math.py: device /, sqrt, normalize, u32->f32, min/max, dot.
+int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_per_s) {
+    if (!accesses_per_s) return RB_ERR_NULL_ARGUMENT;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return RB_ERR_DEVICE;
+    *accesses_per_s = rb::measure_l1_gather(table_bytes ? static_cast<size_t>(table_bytes) : (2u << 20), 512u);
+    return *accesses_per_s > 0.0 ? RB_OK : RB_ERR_DEVICE;
+}
+
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n) {
     if (!a || !b || !out8n) return RB_ERR_NULL_ARGUMENT;
     float *da = nullptr, *db = nullptr, *dout = nullptr;

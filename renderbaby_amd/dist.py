@@ -86,19 +86,25 @@ class ShardedRenderer:
             # the communicator id travels by torch.distributed; every rank must agree on whether the library's
             # RCCL path came up, otherwise all fall back to the torch.distributed gather below
             import torch.distributed as dist
-            ok, why = 1, ""
+            # ncclCommInitRank is collective: a rank whose librccl does not load must not leave the others waiting
+            # inside it.  Every rank first probes RCCL on its own (ncclGetUniqueId loads the library and is not
+            # collective), the ranks agree on the outcome, and only then the communicator is made.
+            ok, why, my_id = 1, "", None
             try:
-                box = [Engine.comm_unique_id() if rank == 0 else None]
-            except Exception as ex:   # librccl not loadable on rank 0
-                box, ok, why = [None], 0, str(ex)
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is None:
-                ok = 0
-            else:
+                my_id = Engine.comm_unique_id()
+            except Exception as ex:   # librccl not loadable on this rank
+                ok, why = 0, str(ex)
+            flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                box = [my_id if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
                 try:
                     self.engine.comm_init_rank(box[0], rank, world)
                 except Exception as ex:
                     ok, why = 0, str(ex)
+            else:
+                ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
@@ -131,9 +137,9 @@ class ShardedRenderer:
         if self.library_gather:   # rb_render: all passes, the RCCL gather, the frame on rank 0 (numpy) / None
             f = self.engine.render_current()
             return None if f is None else f.pixels
+        if self.world == 1:   # rb_render: all passes and the frame read back, as on the root of a sharded run
+            return self.engine.render_current().pixels
         self.render_local()
-        if self.world == 1:
-            return self.local
         import torch.distributed as dist
         # the rows live in the library's own allocation; hand the collective a torch-owned copy (1 MB per
         # rank) so nothing depends on how RCCL treats memory it did not see allocated

@@ -259,6 +259,13 @@ class Engine:
         self._check(self._lib.rb_comm_init_rank(self._h, buf, rank, nranks))
         self.comm_rank = rank
 
+    def comm_info(self):
+        """{"rccl_ranks", "rccl_rank", "gather_ms"}: the communicator as RCCL itself reports it (0 ranks when the
+        exchange does not go through RCCL) and this rank's share of the last gather."""
+        n, r, ms = C.c_uint32(), C.c_uint32(), C.c_float()
+        self._check(self._lib.rb_comm_info(self._h, C.byref(n), C.byref(r), C.byref(ms)))
+        return {"rccl_ranks": n.value, "rccl_rank": r.value, "gather_ms": ms.value}
+
     def render(self, rc: RenderConfig) -> Frame:
         cfg, keep = rc.to_c()
         self._check(self._lib.rb_update(self._h, C.byref(cfg)))

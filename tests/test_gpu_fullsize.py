@@ -75,14 +75,15 @@ def test_c3_fast_bvh_equals_reference_walk_on_the_full_frame():
     s = scenes.mesh_scene(112, 112, 1920, 1080, 8, 5)
     rc = RenderConfig.from_scene(s)
     out = {}
-    for mode in ("exact", "host-sah", "device-ploc", "device-lbvh"):
+    for mode in ("exact", "chunk", "host-sah", "device-ploc", "device-lbvh"):
         e = Engine.new(rc, reference_walk=(mode == "exact"), host_bvh=(mode == "host-sah"), device_bvh=mode.startswith("device"),
                        device_lbvh=(mode == "device-lbvh"))
         e.render(rc)
         out[mode] = (e.read_accumulation(), e.stats()["segments"])
-        assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
+        assert e.fast_bvh_builder()[0] == ("" if mode in ("exact", "chunk") else mode)
+        assert e.last_kernel_name() == {"exact": "k_trace_bvh", "chunk": "k_trace_chunk"}.get(mode, "k_trace_fast")
         e.close()
-    for mode in ("host-sah", "device-ploc", "device-lbvh"):
+    for mode in ("chunk", "host-sah", "device-ploc", "device-lbvh"):
         diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
         assert out["exact"][1] == out[mode][1]
@@ -96,12 +97,12 @@ def test_reference_lamp_scene_fast_walk_equals_reference_walk_at_full_size():
     s = _refscenes.ref_lamp(spp=4)
     rc = RenderConfig.from_scene(s)
     out = {}
-    for mode in ("exact", "host-sah", "device-ploc"):
+    for mode in ("exact", "chunk", "host-sah", "device-ploc"):
         e = Engine.new(rc, reference_walk=(mode == "exact"), host_bvh=(mode == "host-sah"), device_bvh=(mode == "device-ploc"))
         e.render(rc)
         out[mode] = (e.read_accumulation(), e.stats()["segments"])
         e.close()
-    for mode in ("host-sah", "device-ploc"):
+    for mode in ("chunk", "host-sah", "device-ploc"):
         diff = (out["exact"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ"
         assert out["exact"][1] == out[mode][1]

@@ -33,6 +33,27 @@ def test_random_scenes_all_variants(first):
             assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"], (seed, name)
 
 
+@pytest.mark.parametrize("first", [500180, 603375, 700000])
+def test_random_large_frames_all_variants(first, monkeypatch):
+    # Both parity bugs of r02 (a tie between a sphere and an earlier category, seed 500188; large triangles behind a
+    # zero-area one in the second pass of the library's walk, seed 603382) showed only on LARGE frames -- several queue
+    # reservations per wave, up to 300 x 200 pixels and 9 spp -- which the small dose above never makes.  Fifteen such
+    # scenes per range, the two seeds included, every variant.
+    monkeypatch.setenv("FUZZ_BIG", "1")
+    for seed in range(first, first + 15):
+        s = fuzz.random_scene(seed)
+        o_acc, _, o_rgba, o_st = _oracle.render(s)
+        rc = RenderConfig.from_scene(s)
+        for name, kw in fuzz.variants(s):
+            e = Engine.new(rc, **kw)
+            frame = e.render(rc)
+            acc, st = e.read_accumulation(), e.stats()
+            e.close()
+            assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (seed, name)
+            assert np.array_equal(frame.pixels, o_rgba), (seed, name)
+            assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"], (seed, name)
+
+
 def test_sphere_at_exactly_the_t_of_an_earlier_category(monkeypatch):
     # Found by the r02 fuzzer (FUZZ_BIG, seed 500188, pixel (54, 38)): a triangle and a sphere (of 90, so the
     # library's sphere tree is in use) are hit at exactly the same t.  The reference's scan accepts a sphere only

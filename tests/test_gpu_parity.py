@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 KERNELS = [abi.KERNEL_PIXEL, abi.KERNEL_QUEUE, abi.KERNEL_STREAM]
 
 
-_WALK_KW = ("reference_walk", "fast_bvh", "host_bvh", "device_bvh", "device_lbvh", "own_tree")
+_WALK_KW = ("reference_walk", "fast_bvh", "host_bvh", "device_bvh", "device_lbvh", "own_tree", "chunk_walk")
 
 
 def _ref(kw):
     """The tests that compare work counters with the oracle's (or name the reference-walk kernels) pin the
-    reference walk; the library's own tree -- the default for multi-node meshes -- has its own tests."""
+    reference walk; the chunked walk -- the default for multi-node meshes -- and the library's own tree have their
+    own tests."""
     return kw if any(k in kw for k in _WALK_KW) else dict(kw, reference_walk=True)
 
 
@@ -177,12 +178,13 @@ def test_sharded_engines_reassemble_the_single_gpu_frame(kernel, world, stripe_r
 
 
 def _scene_for(which):
-    if which == "mesh":      # multi-node tree: k_trace_bvh / k_trace_bvh_lds / k_trace_fast
+    if which == "mesh":      # multi-node tree: k_trace_chunk / k_trace_bvh / k_trace_bvh_lds / k_trace_fast
         return scenes.mesh_scene(24, 24, 48, 36, 5, 5, seed=3)
     return scenes.spheres_scene(n=3000, width=48, height=36, spp=5, max_depth=5, extent=12.0)   # k_trace_sph
 
 
 @pytest.mark.parametrize("which,kw,kernel_name", [
+    ("mesh", dict(), "k_trace_chunk"), ("mesh", dict(chunk_walk=True), "k_trace_chunk"),
     ("mesh", dict(reference_walk=True), "k_trace_bvh_lds"), ("mesh", dict(lds_mode=1, reference_walk=True), "k_trace_bvh"),
     ("mesh", dict(fast_bvh=True), "k_trace_fast"), ("mesh", dict(own_tree=True), "k_trace_fast"), ("mesh", dict(device_bvh=True), "k_trace_fast"),
     ("mesh", dict(device_lbvh=True), "k_trace_fast"),
@@ -335,7 +337,7 @@ def test_degenerate_frame_sizes(w, h):
 
 
 @pytest.mark.parametrize("which,kw", [("mesh", dict(reference_walk=True)), ("mesh", dict(lds_mode=1, reference_walk=True)),
-                                      ("mesh", dict(fast_bvh=True)), ("mesh", dict(device_bvh=True)), ("mesh", dict(own_tree=True)),
+                                      ("mesh", dict(chunk_walk=True)), ("mesh", dict(fast_bvh=True)), ("mesh", dict(device_bvh=True)), ("mesh", dict(own_tree=True)),
                                       ("spheres", dict())])
 @pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 2, 3), (3, 1, 1, 1), (2, 7, 2, 0), (9, 5, 1, 16)])
 def test_stepped_kernels_on_degenerate_frames(which, kw, w, h, spp, depth):
@@ -389,7 +391,7 @@ def test_sphere_bvh_under_poor_conditioning(n, extent, camscale):
     assert st["segments"] == st2["segments"]
 
 
-@pytest.mark.parametrize("kw,builder", [(dict(fast_bvh=True), "host-sah"), (dict(device_bvh=True), "device-ploc"),
+@pytest.mark.parametrize("kw,builder", [(dict(), ""), (dict(fast_bvh=True), "host-sah"), (dict(device_bvh=True), "device-ploc"),
                                         (dict(device_lbvh=True), "device-lbvh")])
 def test_coincident_triangles(kw, builder):
     # 2 500 copies of one triangle (identical boxes, identical Morton codes, identical t for every ray)

@@ -206,11 +206,12 @@ def _graze_scene(seed, coarse):
 
 
 @pytest.mark.parametrize("coarse", [False, True], ids=["smooth-mesh", "coarse-soup"])
-@pytest.mark.parametrize("builder", ["host-sah", "device-ploc", "device-lbvh"])
+@pytest.mark.parametrize("builder", ["chunk", "host-sah", "device-ploc", "device-lbvh"])
 def test_own_tree_with_rays_in_the_plane_of_a_triangle(coarse, builder):
-    # the culling margin of the library's tree must cover hits the reference reports from a near-zero
-    # determinant (|a| down to 1e-6): eyes in the plane of a triangle, looking along it, 12 scenes each
-    kw = dict(host_bvh=True) if builder == "host-sah" else dict(device_bvh=True, device_lbvh=(builder == "device-lbvh"))
+    # the culling margins of the chunked walk and of the library's tree must cover hits the reference reports from a
+    # near-zero determinant (|a| down to 1e-6): eyes in the plane of a triangle, looking along it, 12 scenes each
+    kw = dict(chunk_walk=True) if builder == "chunk" else dict(host_bvh=True) if builder == "host-sah" else \
+        dict(device_bvh=True, device_lbvh=(builder == "device-lbvh"))
     for seed in range(12):
         sc = _graze_scene(100 + seed, coarse)
         o_acc, _, o_rgba, o_st = _oracle.render(sc)
@@ -218,7 +219,7 @@ def test_own_tree_with_rays_in_the_plane_of_a_triangle(coarse, builder):
         e = Engine.new(rc, **kw)
         f = e.render(rc)
         acc, st = e.read_accumulation(), e.stats()
-        assert e.last_kernel_name() == "k_trace_fast"
+        assert e.last_kernel_name() == ("k_trace_chunk" if builder == "chunk" else "k_trace_fast")
         e.close()
         assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (seed, coarse, builder)
         assert np.array_equal(f.pixels, o_rgba) and st["segments"] == o_st["segments"], (seed, coarse, builder)

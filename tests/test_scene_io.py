@@ -333,7 +333,7 @@ def test_reference_lamp_scene_fixture_matches_the_rscn_file():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "host-sah", "device-ploc", "device-lbvh"])
+@pytest.mark.parametrize("mode", ["exact", "chunk", "host-sah", "device-ploc", "device-lbvh"])
 def test_reference_lamp_scene_bit_exact_on_gpu(mode):
     from renderbaby_amd import Engine, RenderConfig
     s = _refscenes.ref_lamp(width=96, height=96, spp=2)
@@ -343,7 +343,8 @@ def test_reference_lamp_scene_bit_exact_on_gpu(mode):
                    device_bvh=mode.startswith("device"), device_lbvh=(mode == "device-lbvh"))
     f = e.render(rc)
     acc, st = e.read_accumulation(), e.stats()
-    assert e.fast_bvh_builder()[0] == ("" if mode == "exact" else mode)
+    assert e.fast_bvh_builder()[0] == ("" if mode in ("exact", "chunk") else mode)
+    assert (e.last_kernel_name() == "k_trace_chunk") == (mode == "chunk")
     e.close()
     assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(f.pixels, o_rgba)
     assert st["segments"] == o_st["segments"]

@@ -54,7 +54,11 @@ def speed(which):
     if only:
         walks = [w for w in walks if w[0] in only.split(",")]
     for name in which:
-        s = mk[name]()
+        if name.startswith("mesh:"):   # mesh:<n>: an n x n terrain + blob (4 n^2 triangles) at 1080p
+            n = int(name[5:])
+            s = scenes.mesh_scene(n, n, 1920, 1080, int(os.environ.get("SPP", "16")), 5, seed=n)
+        else:
+            s = mk[name]()
         rc = RenderConfig.from_scene(s)
         ref = None
         for wname, kw in walks:

@@ -121,7 +121,8 @@ def variants(scene):
          ("stream-ring", dict(reference_walk=True, queue_batch=256)), ("stream-direct", dict(reference_walk=True, queue_batch=64))]
     if len(scene.bvh_nodes) > 1:
         v += [("stream-noLDS", dict(lds_mode=1, reference_walk=True)), ("stream-perseg", dict(no_leaf_stepping=True, reference_walk=True)),
-              ("default", dict()), ("fast", dict(fast_bvh=True)),
+              ("default", dict()), ("chunk-small-batches", dict(chunk_walk=True, queue_batch=64)),
+              ("fast", dict(fast_bvh=True)),
               ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
     if len(scene.spheres) > 64:
         v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True))]

@@ -170,15 +170,17 @@ def measured_copy_bandwidth(device):
     return 2.0 * n * reps / dt / 1e9
 
 
-def measured_l1_ceiling(device):
-    """Lane accesses per second of divergent 16-byte gathers from an L2-resident table (rb_measure_l1_gather): the
-    ceiling of the L1 / texture-address path on this box.  TCP_TOTAL_CACHE_ACCESSES counts one access per lane of such
-    a load (calibrated with rocprofv3 on the same kernel: profiles/r03_l1_ceiling.txt), so a kernel's counter rate
-    compares with it directly."""
+def measured_l1_ceiling(device, table_bytes=8192):
+    """Lane accesses per second of divergent 16-byte gathers (rb_measure_l1_gather: every lane its own 128-byte line,
+    8-16 loads in flight per lane, best of four launch shapes).  From an 8 KiB table every access hits L1: the ceiling
+    of the L1 / texture-address path on this box (measured 1 200 G/s = 2 per CU-clock).  From a 2 MiB table every
+    access misses L1 and hits L2: the ceiling of the L1 -> L2 request path for gathers (269 G requests/s x 64 B = 17 TB/s,
+    half of the 34.5 TB/s streaming figure).  TCP_TOTAL_CACHE_ACCESSES counts exactly one access per lane of such a load
+    (rocprofv3 on the same kernel: profiles/r03_l1_ceiling.txt), so a kernel's counter rate compares with it directly."""
     import ctypes as C
     from renderbaby_amd import _lib
     v = C.c_double()
-    if _lib.load().rb_measure_l1_gather(device, 0, C.byref(v)) != 0:
+    if _lib.load().rb_measure_l1_gather(device, table_bytes, C.byref(v)) != 0:
         return None
     return v.value
 
@@ -366,15 +368,20 @@ def main():
                       "l1_accesses_per_segment": c.get("tcp_accesses")}
                 l2["frac"] = l2["achieved"] / l2["peak"]
             # the L1 / texture-address path: the kernel's L1 access rate against the rate this box sustains on divergent
-            # 16-byte gathers (one access per lane per load)
+            # 16-byte gathers that hit L1; and its L1 -> L2 request rate against the box's rate on gathers that miss L1
             l1 = None
             l1_peak = measured_l1_ceiling(local_rank)
+            l2_gather = measured_l1_ceiling(local_rank, 2 << 20)
             if c.get("tcp_accesses") and l1_peak:
                 l1 = {"achieved": c["tcp_accesses"] * seg_rate / 1e9, "peak": l1_peak / 1e9, "unit": "G accesses/s",
                       "accesses_per_segment": c["tcp_accesses"],
                       "accesses_per_triangle_test": (c["tcp_accesses"] / (stats["tris_tested"] / max(stats["segments"], 1)))
                       if (stats and stats.get("tris_tested")) else None}
                 l1["frac"] = l1["achieved"] / l1["peak"]
+            if l2 and l2_gather:   # 64-byte requests: against the measured gather rate, not the streaming figure
+                l2["streaming_peak"] = l2["peak"]
+                l2["peak"] = l2_gather * 64.0 / 1e9
+                l2["frac"] = l2["achieved"] / l2["peak"]
             # the binding ceiling = the largest of the fractions
             cands = [("valu", valu)] + ([("l1", l1)] if l1 else []) + ([("l2", l2)] if l2 else []) + [("hbm", hbm)]
             bound, top = max(cands, key=lambda kv: kv[1]["frac"])

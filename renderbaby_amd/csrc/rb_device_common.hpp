@@ -8,12 +8,6 @@
 
 #define DEV __device__ __forceinline__
 
-// Cost-attribution builds (tools/ablate.sh): RB_ABLATE=n repeats one stage on perturbed-but-equal
-// inputs and folds the result into nothing observable, so (time[n] - time[0]) is that stage's cost.
-#ifndef RB_ABLATE
-#define RB_ABLATE 0
-#endif
-
 // Scene data is immutable for the duration of a launch.  Reading it through the
 // constant address space lets the compiler use scalar loads (s_load_*: one
 // fetch per wavefront, operands land in SGPRs) whenever the address is

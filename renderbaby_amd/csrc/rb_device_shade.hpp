@@ -330,37 +330,6 @@ DEV bool segment_post(const KParams& p, Path& pt, const TriHit th, const SegStat
         }
     }
     if (light_idx != 0xFFFFFFFFu) kind = K_LIGHT;
-#if RB_ABLATE == 2
-    {
-        f3 o2 = o;
-        asm volatile("" : "+v"(o2.x));
-        float ct = 1e20f;
-        uint32_t si = 0;
-        for (uint32_t base = 0; base < ns; base += 32u) {
-            const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
-            uint32_t cand = 0u;
-            for (uint32_t k = 0; k < n; k++) {
-                const v4f cr = sph4[(base + k) * 6u];
-                const f3 oc = o2 - mk(cr.x, cr.y, cr.z);
-                const float half_b = dot(oc, d);
-                const float c = dot(oc, oc) - cr.w * cr.w;
-                const float disc = half_b * half_b - a * c;
-                cand |= (disc < 0.0f) ? 0u : (1u << k);
-            }
-            while (cand != 0u) {
-                const uint32_t k = (uint32_t)__ffs((int)cand) - 1u;
-                cand &= cand - 1u;
-                const v4f cr = sph4[(base + k) * 6u];
-                const float t = isect_sphere(o2, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-                if (t > 0.001f && t < ct) {
-                    ct = t;
-                    si = base + k;
-                }
-            }
-        }
-        asm volatile("" ::"v"(ct), "v"(si));
-    }
-#endif
 
     // Sky :604-608
     if (kind == K_NONE) {
@@ -430,14 +399,6 @@ DEV bool segment_post(const KParams& p, Path& pt, const TriHit th, const SegStat
 
     pt.color = pt.color + pt.att * m.emissive;  // :626
 
-#if RB_ABLATE == 3
-    {
-        uint32_t s2 = pt.seed;
-        asm volatile("" : "+v"(s2));
-        const f3 r2 = random_unit_vector(s2);
-        asm volatile("" ::"v"(r2.x), "v"(r2.y), "v"(r2.z));
-    }
-#endif
     // Both scatter branches draw exactly one random unit vector (:472, :488) and nothing else
     // touches the seed, so the rejection loop runs once for the whole wavefront instead of once
     // per branch; likewise the final normalize below is shared.
@@ -481,15 +442,6 @@ DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* s
 template <bool STATS, bool MULTI = true>
 DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     const TriHit th = intersect_bvh<STATS, MULTI>(fresh_params(p), pt.o, pt.d, stack, stride, tl);
-#if RB_ABLATE == 1
-    {
-        f3 o2 = pt.o;
-        asm volatile("" : "+v"(o2.x));
-        Tally<STATS> t2;
-        const TriHit th2 = intersect_bvh<STATS, MULTI>(p, o2, pt.d, stack, stride, t2);
-        asm volatile("" ::"v"(th2.t), "v"(th2.slot));
-    }
-#endif
     return segment_finish<STATS>(p, pt, th, stack, stride, tl);
 }
 

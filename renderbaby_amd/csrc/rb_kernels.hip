@@ -397,15 +397,6 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
                 uint32_t x = 0, y = 0, sample_hash = 0;
                 if (item_pixel(rp, rows, rank, x, y, sample_hash)) {
                     start_path_hashed(rp, x, y, y * r_width + x, sample_hash, pt);
-#if RB_ABLATE == 4
-                    {
-                        Path p2;
-                        uint32_t x2 = x;
-                        asm volatile("" : "+v"(x2));
-                        start_path_hashed(p, x2, y, y * width + x2, sample_hash, p2);
-                        asm volatile("" ::"v"(p2.d.x), "v"(p2.d.y), "v"(p2.d.z), "v"(p2.seed));
-                    }
-#endif
 #if RB_COLOR_COMBINE
                     item = it | direct_mask;
 #else
@@ -663,6 +654,13 @@ constexpr uint32_t kChunkWaveLds = 64u * 32u + 64u * 8u + 128u * 4u;  // per wav
 constexpr unsigned long long kChunkNoHit = 0x60AD78EC00000000ull;     // (bits of 1e20f) << 32: shader.wgsl:283-290
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
+// max(|a|, |b|) in one instruction (fmaxf(fabsf(a), fabsf(b)) compiles to three: each operand is quietened first)
+DEV float max_abs(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // One child slot of a ChunkNode: enter it?  `order` = where the ray enters the inflated box (nearer child first).
 // The slab values are the reference's (shader.wgsl:664-671 on the box as stored); the inflated box is derived from
 // them per axis -- a box grown by mm enters mm |1 / d| earlier and leaves as much later -- so one set of operations
@@ -688,7 +686,7 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float f = cone_admits_grazing(d, cone) ? __uint_as_float(fac & 0xFFFF0000u) : __uint_as_float(fac << 16);
 #endif
     // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
-    const float mx = fmaxf(fabsf(a.x), fabsf(b.x)), my = fmaxf(fabsf(a.y), fabsf(b.y)), mz = fmaxf(fabsf(a.z), fabsf(b.z));
+    const float mx = max_abs(a.x, b.x), my = max_abs(a.y, b.y), mz = max_abs(a.z, b.z);
 #if RB_CHUNK_SP == 0
     const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz))) +
                       2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
@@ -1369,20 +1367,27 @@ __global__ void k_div_exhaustive(uint32_t b_begin, uint32_t ea, uint32_t eb, uin
 
 // Ceiling of the L1 / texture-address path, measured where the bench runs: every lane gathers 16 bytes from its own
 // pseudo-random 128-byte line of a table that fits in L2 (the access pattern of a lane-per-ray tree walk), eight
-// independent loads in flight per lane.  A wave instruction then costs 64 L1 accesses; accesses per second = the
-// number the mesh kernels' TCP_TOTAL_CACHE_ACCESSES rate is compared with (bench.py, roofline.l1).
+// or sixteen independent loads in flight per lane.  A wave instruction then costs 64 L1 accesses (rocprofv3 counts
+// TCP_TOTAL_CACHE_ACCESSES = 1.000 per lane load on it: profiles/r03_l1_ceiling.txt); accesses per second = the number
+// the mesh kernels' TCP_TOTAL_CACHE_ACCESSES rate is compared with (bench.py, roofline.l1).
+template <int INFLIGHT>
 __global__ void __launch_bounds__(256) k_l1_gather(const float4* __restrict__ table, uint32_t lines_mask, uint32_t rounds, float4* sink) {
-    uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    // per-lane line sequence: an odd stride through the table (every line visited, no two lanes of a wave on one line
+    // while the table has >= 64 lines), piece = lane & 7; one multiply-add per load keeps the address arithmetic out of the way
+    const uint32_t lane_id = blockIdx.x * 256u + threadIdx.x;
+    uint32_t line = lane_id * 2654435761u;
+    const uint32_t step = (lane_id * 40503u) | 1u;
+    const uint32_t piece = lane_id & 7u;
     float4 acc = make_float4(0, 0, 0, 0);
     for (uint32_t r = 0; r < rounds; r++) {
-        float4 v[8];
+        float4 v[INFLIGHT];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            h = h * 747796405u + 2891336453u;
-            v[k] = table[(size_t)((h >> 9) & lines_mask) * 8u + ((h >> 3) & 7u)];   // line, 16-byte piece of it
+        for (int k = 0; k < INFLIGHT; k++) {
+            line += step;
+            v[k] = table[(size_t)(line & lines_mask) * 8u + piece];
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc.x += v[k].x, acc.y += v[k].y, acc.z += v[k].z, acc.w += v[k].w;
+        for (int k = 0; k < INFLIGHT; k++) acc.x += v[k].x, acc.y += v[k].y, acc.z += v[k].z, acc.w += v[k].w;
     }
     if (acc.x == 12345.678f) sink[0] = acc;   // never true for the zero-filled table: keeps the loads alive
 }
@@ -1660,9 +1665,10 @@ int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch, void* stream_) {
     return (int)hipGetLastError();
 }
 
-// -> lane accesses per second (0 on failure); table_bytes is rounded down to a power of two >= 64 KiB
+// -> lane accesses per second (0 on failure): the best of a few shapes (8 or 16 loads in flight per lane, 4 or 8 waves
+// per SIMD); table_bytes is rounded down to a power of two >= 8 KiB
 double measure_l1_gather(size_t table_bytes, uint32_t rounds) {
-    size_t lines = 512;
+    size_t lines = 64;
     while (lines * 2 * 128 <= table_bytes) lines *= 2;
     float4 *table = nullptr, *sink = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&table), lines * 128) != hipSuccess) return 0.0;
@@ -1671,16 +1677,19 @@ double measure_l1_gather(size_t table_bytes, uint32_t rounds) {
     hipEvent_t t0, t1;
     (void)hipEventCreate(&t0);
     (void)hipEventCreate(&t1);
-    const uint32_t blocks = device_cu_count_cached() * 8u;
     double best = 0.0;
-    for (int rep = 0; rep < 3; rep++) {
-        (void)hipEventRecord(t0, nullptr);
-        hipLaunchKernelGGL(k_l1_gather, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(lines - 1), rounds, sink);
-        (void)hipEventRecord(t1, nullptr);
-        if (hipEventSynchronize(t1) != hipSuccess) break;
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, t0, t1);
-        if (ms > 0.0f) best = std::max(best, (double)blocks * 256.0 * rounds * 8.0 / (ms * 1e-3));
+    for (int shape = 0; shape < 4; shape++) {
+        const uint32_t inflight = (shape & 1) ? 16u : 8u, blocks = device_cu_count_cached() * ((shape & 2) ? 8u : 4u);
+        for (int rep = 0; rep < 2; rep++) {
+            (void)hipEventRecord(t0, nullptr);
+            if (inflight == 16u) hipLaunchKernelGGL(k_l1_gather<16>, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(lines - 1), rounds, sink);
+            else hipLaunchKernelGGL(k_l1_gather<8>, dim3(blocks), dim3(256), 0, nullptr, table, (uint32_t)(lines - 1), rounds, sink);
+            (void)hipEventRecord(t1, nullptr);
+            if (hipEventSynchronize(t1) != hipSuccess) break;
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, t0, t1);
+            if (ms > 0.0f) best = std::max(best, (double)blocks * 256.0 * rounds * inflight / (ms * 1e-3));
+        }
     }
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);

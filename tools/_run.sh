@@ -1,7 +1,4 @@
 mkdir -p gpurun_out
-{
-NOSTATS=1 WALKS=reference,chunk timeout -k 10 300 python tools/chunk_probe.py speed mesh:4 mesh:8 mesh:12 mesh:18 mesh:24 mesh:40 mesh:70 || exit 1
-} > gpurun_out/small.txt 2>&1
-rc=$?
-grep -v amdgpu.ids gpurun_out/small.txt | awk '/k_trace_/{printf "%-8s %-10s %-16s %8s Mseg/s diff %s\n", $1, $2, $3, $6, $15}'
-exit $rc
+tools/refresh_profiles.sh r03 lamp_reference lamp_ownhost c5 c5_reference c5_owndevice
+echo "=== c5 at its real 4096 spp (one frame, for the frame checksum and the whole-frame rate)"
+timeout -k 10 560 python bench.py --workload c5 --steps 1 --warmup 0 --cpu-seconds 0 --no-stats --no-end-to-end > gpurun_out/c5_full.json 2> gpurun_out/c5_full.err; tail -c 600 gpurun_out/c5_full.json

@@ -126,6 +126,9 @@ def variants(scene):
               ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
     if len(scene.spheres) > 64:
         v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True))]
+    only = os.environ.get("FUZZ_VARIANTS")   # e.g. FUZZ_VARIANTS=default,chunk-small-batches: a focused campaign
+    if only:
+        v = [x for x in v if x[0] in only.split(",")]
     return v
 
 

@@ -13,7 +13,7 @@ tag="$1"; key="$2"; shift 2
 R="$(cd "$(dirname "$0")/.." && pwd)"
 out="$R/gpurun_out/prof_${tag}_${key}"; rm -rf "$out"; mkdir -p "$out"
 args=("$@"); [ ${#args[@]} -eq 0 ] && args=(--workload "$key")
-short=("${args[@]}" --steps 1 --warmup 1 --cpu-seconds 0 --no-stats)
+short=("${args[@]}" --steps 1 --warmup 1 --cpu-seconds 0 --no-stats --no-end-to-end)   # counters are summed over every dispatch of the process
 cd /tmp && export TMPDIR=/tmp
 echo "[profile $key] PMC pass A (SQ)"
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU -d "$out/a" -- python3 "$R/bench.py" "${short[@]}" > "$out/a.log" 2>&1
@@ -24,7 +24,7 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/c" -- python3 "$R/bench.
 echo "[profile $key] PMC pass D (WRITE_SIZE)"
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/d" -- python3 "$R/bench.py" "${short[@]}" > "$out/d.log" 2>&1
 echo "[profile $key] kernel trace"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/e" -- python3 "$R/bench.py" "${args[@]}" --steps 3 --warmup 1 --cpu-seconds 0 > "$out/e.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/e" -- python3 "$R/bench.py" "${args[@]}" --steps 3 --warmup 1 --cpu-seconds 0 --no-end-to-end > "$out/e.log" 2>&1
 cd "$R"
 python3 tools/profile_summary.py "$out" "$tag" "$key" "${args[*]}"
 cp "$(ls $out/e/*/*kernel_stats.csv | head -1)" "profiles/${tag}_${key}_kernel_stats.csv"

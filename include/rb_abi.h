@@ -256,7 +256,7 @@ enum {
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
                                            (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be
                                            missed.  Several times faster on coarse meshes; frames validated equal on the
-                                           BASELINE scenes, but this is the one mode that is not proved exact. */
+                                           BASELINE scenes, but this is the one mode the exactness argument does not cover. */
 };
 
 /* Work counters, summed over every launch since the last rb_reset_stats.

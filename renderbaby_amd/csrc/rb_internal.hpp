@@ -37,13 +37,10 @@ void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode
                       std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
                       float bmax[3]);
 
-// Walk of multi-node meshes when the caller's flags do not say.  The library's own tree is proved to deliver the
-// reference walk's frames, but its second pass -- the hits the reference reports from
-// near-zero determinants -- costs about as much as the reference walk's node phase, so on meshes whose triangles
-// fit in L2 it does not beat the reference walk (C3: 0.45 vs 0.74 G segments/s).  It does once the triangle data
-// outgrows the 32 MB of L2 and the reference walk's ~450 triangle fetches per segment go to HBM (C5: 0.74 vs 0.50):
-// from this many triangles up (64 B each = 24 MiB) the library's tree is the default.
-// RB_FLAG_FAST_BVH / RB_FLAG_REFERENCE_WALK choose explicitly.
+// Walk of multi-node meshes when the caller's flags do not say: the chunked walk (ChunkTree below),
+// at every size.  Should its tree not be buildable (a tree deeper than the LDS stack, a leaf root), the library's own
+// tree of section 4.1 takes over from this many triangles up -- where the reference walk's ~450 triangle fetches per
+// segment go to HBM -- and the reference walk below.  RB_FLAG_FAST_BVH / RB_FLAG_REFERENCE_WALK / RB_FLAG_CHUNK_WALK choose explicitly.
 constexpr uint32_t kOwnTreeDefaultMinTriangles = 393216;
 constexpr uint32_t kDeviceBuildMinTriangles = 16384;  // from here up the library's tree is built on the device by default
 

@@ -894,7 +894,10 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
 #if RB_CHUNK_PIPE
                 Round nx = fetch(0u);
 #endif
-#pragma unroll 1
+#ifndef RB_CHUNK_UNROLL
+#define RB_CHUNK_UNROLL 1
+#endif
+#pragma unroll RB_CHUNK_UNROLL
                 for (uint32_t g0 = 0; g0 < n_units; g0 += 4u) {
 #if RB_CHUNK_PIPE
                     const Round r = nx;

@@ -119,3 +119,56 @@ def test_c5_million_triangle_mesh_matches_the_oracle():
         diff = (out["reference-walk"][0].view(np.uint32) != out[mode][0].view(np.uint32)).any(axis=-1)
         assert diff.sum() == 0, f"{mode}: {int(diff.sum())} of {diff.size} pixels differ from the reference walk"
         assert out[mode][2] == out["reference-walk"][2]
+
+
+# ---- the stepped kernels at the configurations' REAL sample counts (only k_trace had been taken to its
+# real 1024 spp; C3 / C4 / C5 were compared with the oracle at 1-2 spp, which leaves the item decode of their real
+# sample counts -- magic_S, the launch chunking -- unexercised on k_trace_chunk and k_trace_sph).  An engine that owns
+# exactly the oracle's rows (one stripe of the sharded layout) makes that cheap on both sides.
+def _rows_engine(scene, row0, n_rows, **kw):
+    assert row0 % n_rows == 0 and scene.height % n_rows == 0
+    rc = RenderConfig.from_scene(scene)
+    e = Engine.new(rc, shard_rank=row0 // n_rows, shard_count=scene.height // n_rows, stripe_rows=n_rows, **kw)
+    f = e.render(rc)
+    acc, st, name = e.read_accumulation(), e.stats(), e.last_kernel_name()
+    assert e.local_rows() == (n_rows, n_rows) and e.global_row(0) == row0
+    e.close()
+    return f.pixels, acc, st, name
+
+
+def test_c3_at_its_real_256_spp_on_four_rows():
+    s = scenes.mesh_c3()
+    assert s.total_samples == 256 and (s.width, s.height) == (1920, 1080)
+    rows = (704, 708)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows)
+    px, acc, st, name = _rows_engine(s, rows[0], 4)
+    assert name == "k_trace_chunk"
+    assert np.array_equal(acc[:4].view(np.uint32), o_acc[rows[0]:rows[1]].view(np.uint32))
+    assert np.array_equal(px[:4], o_rgba[rows[0]:rows[1]])
+    assert st["segments"] == o_st["segments"] and st["paths"] == o_st["paths"] == 4 * 1920 * 256
+
+
+def test_c4_at_its_real_64_spp_on_a_window():
+    s = scenes.spheres_scene()   # 10^6 spheres, 4096 x 4096, 64 spp, depth 5
+    assert s.total_samples == 64 and len(s.spheres) == 1_000_000
+    rows, cols = (2040, 2042), (2044, 2048)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows, cols=cols)
+    assert o_st["spheres_tested"] == o_st["segments"] * 1_000_000   # the oracle really scanned them all
+    px, acc, st, name = _rows_engine(s, rows[0], 2)
+    assert name == "k_trace_sph"
+    assert np.array_equal(acc[:2, cols[0]:cols[1]].view(np.uint32), o_acc[rows[0]:rows[1], cols[0]:cols[1]].view(np.uint32))
+    assert np.array_equal(px[:2, s.width - cols[1]:s.width - cols[0]], o_rgba[rows[0]:rows[1], s.width - cols[1]:s.width - cols[0]])
+    assert st["paths"] == 2 * 4096 * 64
+
+
+def test_c5_at_its_real_4096_spp_on_a_window():
+    s = scenes.mesh_c5()
+    assert s.total_samples == 4096 and int(s.uniforms["max_depth"][0]) == 16 and len(s.bvh_triangles) == 1_048_578
+    rows, cols = (1500, 1501), (1900, 1964)
+    o_acc, _, o_rgba, o_st = _oracle.render(s, rows=rows, cols=cols)
+    assert o_st["mesh_hits"] > 0
+    px, acc, st, name = _rows_engine(s, rows[0], 1)
+    assert name == "k_trace_chunk"
+    assert np.array_equal(acc[:1, cols[0]:cols[1]].view(np.uint32), o_acc[rows[0]:rows[1], cols[0]:cols[1]].view(np.uint32))
+    assert np.array_equal(px[:1, s.width - cols[1]:s.width - cols[0]], o_rgba[rows[0]:rows[1], s.width - cols[1]:s.width - cols[0]])
+    assert st["paths"] == 3840 * 4096

@@ -26,7 +26,8 @@ pub const RB_FLAG_REFERENCE_WALK: u32 = 32;      // force the reference's walk (
 pub const RB_FLAG_HOST_BVH: u32 = 64;            // build that tree on the host
 pub const RB_FLAG_GATHER_PEER_COPY: u32 = 128;   // rb_create_multi without RCCL
 pub const RB_FLAG_NO_RUN_AHEAD: u32 = 256;       // iterator: no pass started ahead of the read-back
-pub const RB_FLAG_SKIP_NEAR_DEGENERATE: u32 = 512; // the library's tree without its second pass (not proved exact)
+pub const RB_FLAG_SKIP_NEAR_DEGENERATE: u32 = 512; // the library's tree without its second pass (outside the exactness argument)
+pub const RB_FLAG_CHUNK_WALK: u32 = 1024;        // the chunked walk: the default for multi-node meshes, the flag only names it
 pub const RB_COMM_ID_BYTES: usize = 128;
 
 unsafe extern "C" {
@@ -37,6 +38,8 @@ unsafe extern "C" {
     /// one process per device: rank 0 makes the id, every rank joins with its shard
     pub fn rb_comm_unique_id(id_out: *mut u8) -> c_int;
     pub fn rb_comm_init_rank(e: *mut RbEngine, id: *const u8, rank: u32, nranks: u32) -> c_int;
+    /// the communicator as RCCL reports it (0 ranks: nothing goes through RCCL) and this rank's share of the last gather
+    pub fn rb_comm_info(e: *mut RbEngine, rccl_ranks: *mut u32, rccl_rank: *mut u32, last_gather_ms: *mut f32) -> c_int;
     /// page-locked frame memory: read-backs into it are DMA copies that overlap the next pass
     pub fn rb_host_alloc(bytes: usize) -> *mut c_void;
     pub fn rb_host_free(p: *mut c_void);

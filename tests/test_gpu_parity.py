@@ -413,3 +413,80 @@ def test_coincident_triangles(kw, builder):
     assert eng.fast_bvh_builder()[0] == builder
     eng.close()
     assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(frame.pixels, o_rgba)
+
+
+# ---- trees the reference's builder would never make, but the boundary accepts (RenderConfig.bvh_nodes is the caller's):
+# the walk must reproduce what shader.wgsl:282-392 does WITH THAT TREE, whatever its quality
+def _py_tree(tris, max_leaf, rng=None, lopsided=False):
+    """A median-split tree in the reference's node layout with leaves of up to `max_leaf` triangles; `lopsided` cuts
+    every range 1 : 7 instead of in halves (a deep, unbalanced tree)."""
+    cent = (tris["v0"] + tris["v1"] + tris["v2"]) / np.float32(3.0)
+    lo = np.minimum(np.minimum(tris["v0"], tris["v1"]), tris["v2"])
+    hi = np.maximum(np.maximum(tris["v0"], tris["v1"]), tris["v2"])
+    nodes, order = [], []
+
+    def build(ids):
+        me = len(nodes)
+        nodes.append(None)
+        bmin, bmax = lo[ids].min(axis=0), hi[ids].max(axis=0)
+        if len(ids) <= max_leaf:
+            nodes[me] = (bmin, bmax, 0, 0, len(order), len(ids))
+            order.extend(ids.tolist())
+            return me
+        ext = cent[ids].max(axis=0) - cent[ids].min(axis=0)
+        ids = ids[np.argsort(cent[ids, int(np.argmax(ext))], kind="stable")]
+        mid = max(1, len(ids) // 8) if lopsided else len(ids) // 2
+        left, right = build(ids[:mid]), build(ids[mid:])
+        nodes[me] = (bmin, bmax, left, right, 0, 0)
+        return me
+    build(np.arange(len(tris)))
+    out = np.zeros(len(nodes), dtype=abi.BVH_NODE)
+    for i, (bmin, bmax, l, r, first, count) in enumerate(nodes):
+        out[i]["aabb_min"], out[i]["aabb_max"] = bmin, bmax
+        out[i]["left"], out[i]["right"], out[i]["first_primitive"], out[i]["primitive_count"] = l, r, first, count
+    return out, np.asarray(order, dtype=np.uint32)
+
+
+def _with_tree(s, nodes, indices):
+    u = s.uniforms.copy()
+    u["bvh_node_count"] = len(nodes)
+    return scenes.Scene(u, s.spheres, s.lights, s.meshes, nodes, indices, s.bvh_triangles, s.uvs, s.textures)
+
+
+@pytest.mark.parametrize("shape", ["leaves-of-300", "leaves-of-5", "lopsided", "boxes-shrunk", "boxes-grown", "boxes-shifted"])
+@pytest.mark.parametrize("kw", [dict(), dict(reference_walk=True), dict(fast_bvh=True)], ids=["chunk", "reference", "own-tree"])
+def test_caller_made_trees(shape, kw):
+    base = scenes.mesh_scene(20, 20, 72, 48, 3, 5, seed=31)   # 1 600 triangles + light quad
+    tris = base.bvh_triangles
+    rng = np.random.default_rng(5)
+    if shape == "leaves-of-300":
+        nodes, idx = _py_tree(tris, 300)
+    elif shape == "leaves-of-5":
+        nodes, idx = _py_tree(tris, 5)
+    elif shape == "lopsided":
+        nodes, idx = _py_tree(tris, 40, lopsided=True)
+    else:   # the reference builder's tree with every box made wrong in its own way: the boxes no longer contain their triangles
+        nodes, idx = base.bvh_nodes.copy(), base.bvh_indices.copy()
+        c = (nodes["aabb_min"] + nodes["aabb_max"]) * np.float32(0.5)
+        h = (nodes["aabb_max"] - nodes["aabb_min"]) * np.float32(0.5)
+        if shape == "boxes-shrunk":
+            h = h * rng.uniform(0.3, 0.9, h.shape).astype(np.float32)
+        elif shape == "boxes-grown":
+            h = h * rng.uniform(1.0, 3.0, h.shape).astype(np.float32)
+        else:
+            c = c + h * rng.uniform(-0.8, 0.8, h.shape).astype(np.float32)
+        nodes["aabb_min"], nodes["aabb_max"] = c - h, c + h
+        nodes["aabb_min"][0], nodes["aabb_max"][0] = base.bvh_nodes["aabb_min"][0], base.bvh_nodes["aabb_max"][0]   # keep the root: something must be seen
+    s = _with_tree(base, nodes, idx)
+    assert len(s.bvh_nodes) > 1
+    o_acc, _, o_rgba, o_st = _oracle.render(s)
+    assert o_st["mesh_hits"] > 0
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc, **kw)
+    f = e.render(rc)
+    acc, st, name = e.read_accumulation(), e.stats(), e.last_kernel_name()
+    e.close()
+    if not kw:
+        assert name == "k_trace_chunk"
+    assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (shape, name)
+    assert np.array_equal(f.pixels, o_rgba) and st["segments"] == o_st["segments"], (shape, name)

@@ -509,6 +509,29 @@ bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         }
     }
     if (slots.empty() || slots.size() >= (1u << 28)) return false;
+    // ---- This walk leans on two properties every tree of the reference's builder has (bvh.rs:100-123) and a caller's own
+    // tree need not: a child's box lies inside its parent's (the chain shortcut of reference_would_test), and a leaf's
+    // box contains its triangles (the second pass culls on the reference's boxes).  A tree without them keeps the
+    // reference walk (found by tests/test_gpu_parity.py::test_caller_made_trees, r03: boxes shrunk by hand).
+    for (uint32_t ni : order) {
+        const rb_bvh_node& n = ref_nodes[ni];
+        auto inside = [&](const float* mn, const float* mx) {
+            for (int a = 0; a < 3; ++a)
+                if (!(n.aabb_min[a] <= mn[a] && mx[a] <= n.aabb_max[a])) return false;
+            return true;
+        };
+        if (n.primitive_count > 0) {
+            for (uint32_t i = 0; i < n.primitive_count; ++i) {
+                const uint32_t slot = n.first_primitive + i;
+                if (slot >= index_len || indices[slot] >= tri_count) continue;
+                const rb_gpu_triangle& t = tris[indices[slot]];
+                if (!inside(t.v0, t.v0) || !inside(t.v1, t.v1) || !inside(t.v2, t.v2)) return false;
+            }
+        } else {
+            if (n.left < node_count && !inside(ref_nodes[n.left].aabb_min, ref_nodes[n.left].aabb_max)) return false;
+            if (n.right < node_count && !inside(ref_nodes[n.right].aabb_min, ref_nodes[n.right].aabb_max)) return false;
+        }
+    }
     // ---- per reference node: the cone of the triangle normals below it (bottom-up: leaves from their triangles,
     // inner nodes by merging their children's cones), for the walk's second pass over near-degenerate hits
     std::vector<DCone> cones(node_count);
@@ -772,7 +795,11 @@ struct ChunkBuilder {
         const int axis = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);
         std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
                          [&](const ChunkItem& x, const ChunkItem& y) { return centroid(x, axis) < centroid(y, axis); });
-        const ChunkInfo l = build(lo, mid), rr = build(mid, hi);
+        return join(build(lo, mid), build(mid, hi), lo, mid, hi);
+    }
+    // one of the library's own nodes over the subtrees of items [lo, mid) and [mid, hi)
+    ChunkInfo join(const ChunkInfo& l, const ChunkInfo& rr, size_t lo, size_t mid, size_t hi) {
+        ChunkInfo r;
         ChunkNode n{};
         float mn[3], mx[3];
         tight(lo, mid, mn, mx);
@@ -787,6 +814,24 @@ struct ChunkBuilder {
         r.depth = 1 + std::max(l.depth, rr.depth);
         tight(lo, hi, r.mn, r.mx);
         return r;
+    }
+    // The triangles of one reference leaf.  A chunk's margin is its worst triangle's: one wall-sized triangle among a
+    // lamp's thousands (the reference's median splits put them in the same leaf) gives the whole chunk an unbounded
+    // margin and a cone that admits every ray, so it would be tested on every visit of the leaf.  Triangles whose
+    // determinant-floor bound is far above the leaf's typical one are therefore split off first, into subtrees of
+    // their own (and again among themselves).
+    ChunkInfo build_leaf(size_t lo, size_t hi) {
+        const size_t count = hi - lo;
+        if (count >= 2) {
+            std::vector<double> caps(count);
+            for (size_t i = 0; i < count; ++i) caps[i] = items[lo + i].cap;
+            std::nth_element(caps.begin(), caps.begin() + count / 2, caps.end());
+            const double thr = 8.0 * caps[count / 2];
+            const auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const ChunkItem& x) { return x.cap <= thr; });
+            const size_t mid = static_cast<size_t>(it - items.begin());
+            if (mid > lo && mid < hi) return join(build(lo, mid), build_leaf(mid, hi), lo, mid, hi);
+        }
+        return build(lo, hi);
     }
 };
 }  // namespace
@@ -849,7 +894,7 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 for (int a = 0; a < 3; ++a) it.n[a] = b.n[a];
                 items.push_back(it);
             }
-            if (!items.empty()) r = cb.build(0, items.size());
+            if (!items.empty()) r = cb.build_leaf(0, items.size());
         } else {
             const bool hl = n.left < node_count, hr = n.right < node_count;
             const ChunkInfo none;

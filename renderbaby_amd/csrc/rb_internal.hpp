@@ -126,7 +126,11 @@ struct alignas(16) ChunkNode {
     float rcone[4];
 };
 static_assert(sizeof(ChunkNode) == 96, "ChunkNode is 96 B");
-constexpr uint32_t kChunkTris = 16;           // triangles per chunk = lanes per (ray, chunk) unit
+#ifndef RB_CHUNK_TRIS
+#define RB_CHUNK_TRIS 16
+#endif
+constexpr uint32_t kChunkTris = RB_CHUNK_TRIS;   // triangles per chunk = lanes per (ray, chunk) unit: 8, 16 or 32
+static_assert(kChunkTris == 8 || kChunkTris == 16 || kChunkTris == 32, "a chunk is tested by 8, 16 or 32 lanes");
 constexpr uint32_t kChunkNone = 0xFFFFFFFFu;
 constexpr uint32_t kChunkLeaf = 0x80000000u, kChunkExact = 0x40000000u;
 struct ChunkTree {

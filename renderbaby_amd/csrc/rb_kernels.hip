@@ -864,6 +864,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                 const cf4p ca = (cf4p)p.chunk_a, cb = (cf4p)p.chunk_b, cc = (cf4p)p.chunk_c;
                 // one round = four pairs; the next round's ray records and triangle pieces are requested before
                 // this round's are tested
+                constexpr uint32_t kPairsPerRound = 64u / kChunkTris;
                 struct Round {
                     v4f r0, r1, a, b, c;
                     uint32_t rl;
@@ -871,14 +872,14 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                 };
                 auto fetch = [&](uint32_t g0) {
                     Round r;
-                    const uint32_t g = g0 + (lane >> 4);
+                    const uint32_t g = g0 + lane / kChunkTris;
                     const bool ok = g < n_units;
                     const uint32_t e = units[ok ? g : 0u];
                     r.rl = e & 63u;
                     r.r0 = rayrec[r.rl * 2u];
                     r.r1 = rayrec[r.rl * 2u + 1u];
                     const uint32_t ref = __float_as_uint((e & 64u) ? r.r1.w : r.r0.w), first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 31u) + 1u;
-                    const uint32_t j = lane & 15u;
+                    const uint32_t j = lane & (kChunkTris - 1u);
                     r.valid = ok && j < cnt;
                     const uint32_t pos = first + (j < cnt ? j : 0u);
                     r.a = ca[pos];
@@ -887,7 +888,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                     return r;
                 };
 #if RB_CHUNK_PROFILE == 1
-                prof[2] += (n_units + 3u) / 4u; prof[3] += n_units;
+                prof[2] += (n_units + kPairsPerRound - 1u) / kPairsPerRound; prof[3] += n_units;
 #elif RB_CHUNK_PROFILE == 2
                 prof[2]++;
 #endif
@@ -898,10 +899,10 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
 #define RB_CHUNK_UNROLL 1
 #endif
 #pragma unroll RB_CHUNK_UNROLL
-                for (uint32_t g0 = 0; g0 < n_units; g0 += 4u) {
+                for (uint32_t g0 = 0; g0 < n_units; g0 += kPairsPerRound) {
 #if RB_CHUNK_PIPE
                     const Round r = nx;
-                    if (g0 + 4u < n_units) nx = fetch(g0 + 4u);
+                    if (g0 + kPairsPerRound < n_units) nx = fetch(g0 + kPairsPerRound);
 #else
                     const Round r = fetch(g0);
 #endif

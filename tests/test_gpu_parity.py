@@ -417,9 +417,9 @@ def test_coincident_triangles(kw, builder):
 
 # ---- trees the reference's builder would never make, but the boundary accepts (RenderConfig.bvh_nodes is the caller's):
 # the walk must reproduce what shader.wgsl:282-392 does WITH THAT TREE, whatever its quality
-def _py_tree(tris, max_leaf, rng=None, lopsided=False):
-    """A median-split tree in the reference's node layout with leaves of up to `max_leaf` triangles; `lopsided` cuts
-    every range 1 : 7 instead of in halves (a deep, unbalanced tree)."""
+def _py_tree(tris, max_leaf, rng=None, lopsided=0):
+    """A median-split tree in the reference's node layout with leaves of up to `max_leaf` triangles; `lopsided` = k cuts
+    every range 1 : k - 1 instead of in halves (a deep, unbalanced tree)."""
     cent = (tris["v0"] + tris["v1"] + tris["v2"]) / np.float32(3.0)
     lo = np.minimum(np.minimum(tris["v0"], tris["v1"]), tris["v2"])
     hi = np.maximum(np.maximum(tris["v0"], tris["v1"]), tris["v2"])
@@ -435,7 +435,7 @@ def _py_tree(tris, max_leaf, rng=None, lopsided=False):
             return me
         ext = cent[ids].max(axis=0) - cent[ids].min(axis=0)
         ids = ids[np.argsort(cent[ids, int(np.argmax(ext))], kind="stable")]
-        mid = max(1, len(ids) // 8) if lopsided else len(ids) // 2
+        mid = max(1, len(ids) // lopsided) if lopsided else len(ids) // 2
         left, right = build(ids[:mid]), build(ids[mid:])
         nodes[me] = (bmin, bmax, left, right, 0, 0)
         return me
@@ -453,7 +453,7 @@ def _with_tree(s, nodes, indices):
     return scenes.Scene(u, s.spheres, s.lights, s.meshes, nodes, indices, s.bvh_triangles, s.uvs, s.textures)
 
 
-@pytest.mark.parametrize("shape", ["leaves-of-300", "leaves-of-5", "lopsided", "boxes-shrunk", "boxes-grown", "boxes-shifted"])
+@pytest.mark.parametrize("shape", ["leaves-of-300", "leaves-of-5", "lopsided", "too-deep-for-the-chunk-stack", "boxes-shrunk", "boxes-grown", "boxes-shifted"])
 @pytest.mark.parametrize("kw", [dict(), dict(reference_walk=True), dict(fast_bvh=True)], ids=["chunk", "reference", "own-tree"])
 def test_caller_made_trees(shape, kw):
     base = scenes.mesh_scene(20, 20, 72, 48, 3, 5, seed=31)   # 1 600 triangles + light quad
@@ -464,7 +464,9 @@ def test_caller_made_trees(shape, kw):
     elif shape == "leaves-of-5":
         nodes, idx = _py_tree(tris, 5)
     elif shape == "lopsided":
-        nodes, idx = _py_tree(tris, 40, lopsided=True)
+        nodes, idx = _py_tree(tris, 40, lopsided=4)
+    elif shape == "too-deep-for-the-chunk-stack":   # ~28 levels: more than the 32-entry LDS stack leaves room for below the caller's leaves
+        nodes, idx = _py_tree(tris, 40, lopsided=8)
     else:   # the reference builder's tree with every box made wrong in its own way: the boxes no longer contain their triangles
         nodes, idx = base.bvh_nodes.copy(), base.bvh_indices.copy()
         c = (nodes["aabb_min"] + nodes["aabb_max"]) * np.float32(0.5)
@@ -486,7 +488,7 @@ def test_caller_made_trees(shape, kw):
     f = e.render(rc)
     acc, st, name = e.read_accumulation(), e.stats(), e.last_kernel_name()
     e.close()
-    if not kw:
-        assert name == "k_trace_chunk"
+    if not kw:   # the default: the chunked walk, or -- when its tree would not fit the stack -- the reference walk
+        assert name == ("k_trace_bvh" if shape == "too-deep-for-the-chunk-stack" else "k_trace_chunk")
     assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), (shape, name)
     assert np.array_equal(f.pixels, o_rgba) and st["segments"] == o_st["segments"], (shape, name)

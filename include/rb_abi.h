@@ -419,6 +419,13 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
 /* Test hook: evaluates the device's f32 /, sqrt, normalize, u32->f32, min/max and
  * dot on n input pairs (out8n: 8*n floats) so tests can check them against
  * IEEE-754 results computed on the host. */
+/* Test aid (host only, no device): builds the chunked walk's tree for this mesh and this caller tree and checks the
+ * structural invariants the kernel relies on (every valid slot in exactly one chunk, ranks consistent, references in range,
+ * depth within the stack, per child slot an unbounded margin or a box and a bound that cover the triangles below).
+ * out6 = {built (0: this tree is left to another walk), nodes, positions, depth, chunks, child slots with an unbounded
+ * margin}; a violated invariant is RB_ERR_INVALID_BVH with rb_last_error(NULL) naming it. */
+int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh_node* nodes, size_t n_nodes, const uint32_t* indices,
+                        size_t n_indices, uint64_t out6[6]);
 /* Measurement aid for the roofline record (bench.py): the rate at which this device serves divergent 16-byte gathers --
  * every lane its own 128-byte line of a table of `table_bytes` (0 = 2 MiB, L2-resident) -- in lane accesses per second:
  * the ceiling of the L1 / texture-address path that a lane-per-ray tree walk runs into. */

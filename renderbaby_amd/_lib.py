@@ -70,6 +70,7 @@ def load():
         "rb_reset_stats": (i32, [vp]),
         "rb_last_dispatch_ms": (i32, [vp, P(C.c_float)]),
         "rb_bvh_build": (i32, [vp, sz, vp, sz, P(sz), vp]),
+        "rb_debug_chunk_tree": (i32, [vp, sz, vp, sz, vp, sz, vp]),
         "rb_measure_l1_gather": (i32, [i32, C.c_uint64, P(C.c_double)]),
         "rb_debug_math": (i32, [vp, vp, vp, u32]),
         "rb_debug_rcp_exhaustive": (i32, [u32, vp]),
@@ -105,4 +106,4 @@ EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_unique_id", 
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_iter_set_passes_per_frame", "rb_last_error",
            "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
            "rb_device_rgba", "rb_host_alloc", "rb_host_free", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",
-           "rb_last_dispatch_ms", "rb_bvh_build", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_version", "rb_device_name"]
+           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_version", "rb_device_name"]

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <future>
 #include <cmath>
 #include <cstdlib>
@@ -923,6 +924,77 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
     out.depth = info[0].depth;
     if (out.root == kChunkNone || out.nodes.size() >= (1u << 30)) return false;
     return out.depth + 1u <= stack_limit;
+}
+
+
+// Structural invariants of a ChunkTree against the triangles it was made from -- what k_trace_chunk relies on without
+// checking: every valid slot in exactly one chunk, ranks and positions consistent, references in range, no node reached
+// twice, depth within the stack, and per child slot either an unbounded margin or (a) a box that contains every triangle
+// below it and (b) a determinant-floor bound no smaller than any of theirs.  `why` names the first violation.
+bool chunk_tree_check(const ChunkTree& t, const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      uint32_t stack_limit, std::string& why) {
+    const size_t n = t.pos_slot.size();
+    if (t.pos_rank.size() != n || t.rank_slot.size() != n) { why = "position / rank arrays differ in length"; return false; }
+    std::vector<uint8_t> seen_rank(n, 0), seen_pos(n, 0), seen_node(t.nodes.size(), 0);
+    for (size_t p = 0; p < n; ++p) {
+        const uint32_t r = t.pos_rank[p], slot = t.pos_slot[p];
+        if (r >= n || seen_rank[r]) { why = "rank " + std::to_string(r) + " missing or used twice"; return false; }
+        seen_rank[r] = 1;
+        if (t.rank_slot[r] != slot) { why = "rank_slot disagrees with pos_slot at position " + std::to_string(p); return false; }
+        if (slot >= index_len || indices[slot] >= tri_count) { why = "position " + std::to_string(p) + " holds an invalid slot"; return false; }
+    }
+    auto bf16 = [](uint32_t h) { const uint32_t b = h << 16; float f; std::memcpy(&f, &b, 4); return f; };
+    struct Range { float mn[3], mx[3]; double cap; uint32_t depth; };
+    // post-order over the tree: the ranges of a node's two children are checked against its slots
+    std::function<bool(uint32_t, Range&)> visit = [&](uint32_t ref, Range& out) -> bool {
+        for (int a = 0; a < 3; ++a) { out.mn[a] = kInf; out.mx[a] = -kInf; }
+        out.cap = 0.0;
+        out.depth = 0;
+        if (ref & kChunkLeaf) {
+            const uint32_t first = ref & 0x03FFFFFFu, count = ((ref >> 26) & 31u) + 1u;
+            if (count > kChunkTris || static_cast<size_t>(first) + count > n) { why = "chunk [" + std::to_string(first) + ", +" + std::to_string(count) + ") out of range"; return false; }
+            for (uint32_t p = first; p < first + count; ++p) {
+                if (seen_pos[p]) { why = "position " + std::to_string(p) + " is in two chunks"; return false; }
+                seen_pos[p] = 1;
+                const rb_gpu_triangle& g = tris[indices[t.pos_slot[p]]];
+                double l1 = 0, l2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    out.mn[a] = std::min(out.mn[a], std::min(g.v0[a], std::min(g.v1[a], g.v2[a])));
+                    out.mx[a] = std::max(out.mx[a], std::max(g.v0[a], std::max(g.v1[a], g.v2[a])));
+                    l1 += double(g.v1[a] - g.v0[a]) * double(g.v1[a] - g.v0[a]);
+                    l2 += double(g.v2[a] - g.v0[a]) * double(g.v2[a] - g.v0[a]);
+                }
+                out.cap = std::max(out.cap, std::max(l1, l2) * 1e6);
+            }
+            return true;
+        }
+        const uint32_t ni = ref & 0x3FFFFFFFu;
+        if (ni >= t.nodes.size() || seen_node[ni]) { why = "node " + std::to_string(ni) + " out of range or reached twice"; return false; }
+        seen_node[ni] = 1;
+        const ChunkNode& c = t.nodes[ni];
+        const struct { const float* mn; const float* mx; uint32_t ref, fac; } slot[2] = {{c.lmin, c.lmax, c.lref, c.lfac}, {c.rmin, c.rmax, c.rref, c.rfac}};
+        for (const auto& sl : slot) {
+            if (sl.ref == kChunkNone) continue;
+            Range r;
+            if (!visit(sl.ref, r)) return false;
+            out.depth = std::max(out.depth, r.depth);
+            out.cap = std::max(out.cap, r.cap);
+            for (int a = 0; a < 3; ++a) { out.mn[a] = std::min(out.mn[a], r.mn[a]); out.mx[a] = std::max(out.mx[a], r.mx[a]); }
+            if (sl.fac == 0x7F807F80u) continue;   // always entered
+            for (int a = 0; a < 3; ++a)
+                if (!(sl.mn[a] <= r.mn[a] && r.mx[a] <= sl.mx[a])) { why = "a child box of node " + std::to_string(ni) + " does not contain its triangles and may still be culled"; return false; }
+            if (!(double(bf16(sl.fac >> 16)) >= r.cap)) { why = "a child of node " + std::to_string(ni) + " understates the determinant-floor bound below it"; return false; }
+        }
+        out.depth += 1;
+        return true;
+    };
+    Range root;
+    if (t.root == kChunkNone || !visit(t.root, root)) { if (why.empty()) why = "no root"; return false; }
+    for (size_t p = 0; p < n; ++p)
+        if (!seen_pos[p]) { why = "position " + std::to_string(p) + " is in no chunk"; return false; }
+    if (root.depth != t.depth) { why = "depth " + std::to_string(t.depth) + " recorded, " + std::to_string(root.depth) + " found"; return false; }
+    if (t.depth + 1u > stack_limit) { why = "deeper than the stack"; return false; }
+    return true;
 }
 
 }  // namespace rb

@@ -142,6 +142,8 @@ struct ChunkTree {
 };
 bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                       const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, ChunkTree& out);
+bool chunk_tree_check(const ChunkTree& t, const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
+                      uint32_t stack_limit, std::string& why);   // the structural invariants k_trace_chunk relies on
 
 // ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
 struct DeviceTreeInfo {

@@ -778,9 +778,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         }
 #endif
     };
-#ifdef RB_CHUNK_PROFILE  // -DRB_CHUNK_PROFILE=1|2: pass occupancy instead of the work counters (tools/chunk_probe.py profile)
-    unsigned long long prof[5] = {0, 0, 0, 0, 0};
-#endif
 
     for (;;) {
         // ---- (1) hand items to idle lanes
@@ -823,9 +820,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
             const bool at_node = state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) == 0u;
             const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
             if (n == 0u || (it > 0 && n < (uint32_t)RB_CHUNK_NODE_LANES)) break;
-#if RB_CHUNK_PROFILE == 1
-            prof[0]++; prof[1] += n;
-#endif
             if (at_node) {
                 if (!chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl)) {
 #if RB_CHUNK_DEFER
@@ -887,11 +881,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                     r.c = cc[pos];
                     return r;
                 };
-#if RB_CHUNK_PROFILE == 1
-                prof[2] += (n_units + kPairsPerRound - 1u) / kPairsPerRound; prof[3] += n_units;
-#elif RB_CHUNK_PROFILE == 2
-                prof[2]++;
-#endif
 #if RB_CHUNK_PIPE
                 Round nx = fetch(0u);
 #endif
@@ -938,13 +927,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         {
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(state == FINISH));
             const uint32_t n_trav = (uint32_t)__popcll(__ballot(state == TRAV));
-#if RB_CHUNK_PROFILE == 1
-            if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u)) prof[4]++;
-#elif RB_CHUNK_PROFILE == 2
-            prof[0]++;
-            if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u)) { prof[1] += n_fin; prof[4]++; }
-            prof[3] += n_trav;
-#endif
             if (n_fin != 0u && (n_fin >= (uint32_t)RB_CHUNK_FINISH_LANES || n_trav == 0u) && state == FINISH) {
                 TriHit th;
                 th.hit = key != kChunkNoHit;
@@ -971,11 +953,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         }
     }
     flush_tally<STATS>(tl, p.counters);
-#ifdef RB_CHUNK_PROFILE
-    // 1: node passes, lanes in them, leaf rounds, pairs in them, finish passes; 2: outer iterations, lanes shaded, leaf
-    // phases, walking lanes summed over the iterations, finish passes -> the five STATS counter slots
-    if (lane == 0u) for (int i = 0; i < 5; i++) atomicAdd(&p.counters[2 + i], prof[i]);
-#endif
 }
 
 // RB_FLAG_FAST_BVH, stepped: the opt-in walk (FastWalk, rb_device_intersect.hpp) with the same
@@ -1090,9 +1067,6 @@ DEV void trace_stepped(const KParams& p) {
     pt.depth = 0;
     Walk w;
     w.init(p);
-#ifdef RB_FAST_PROFILE  // -DRB_FAST_PROFILE: pass occupancy instead of the work counters (tools/ab.sh, RB_PRINT=1)
-    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
-#endif
 
     for (;;) {
         // ---- (1) hand items to idle lanes
@@ -1148,11 +1122,6 @@ DEV void trace_stepped(const KParams& p) {
             const bool at_node = state == TRAV && !w.at_leaf();
             const bool at_leaf = state == TRAV && w.at_leaf();
             const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-#ifdef RB_FAST_PROFILE
-            if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
-                if (n_leaf) { prof[2]++; prof[3] += n_leaf; } else { prof[0]++; prof[1] += n_node; }
-            } else { prof[0]++; prof[1] += n_node; }
-#endif
             if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
                 if (at_leaf && !w.leaf_step(p, stack, tl)) state = FINISH;
                 if (n_leaf == 0u && at_node && !w.node_step(p, stack, tl)) state = FINISH;
@@ -1167,9 +1136,6 @@ DEV void trace_stepped(const KParams& p) {
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
         }
 
-#ifdef RB_FAST_PROFILE
-        { const uint32_t nf = (uint32_t)__popcll(__ballot(state == FINISH)); if (nf) { prof[4]++; prof[5] += nf; } }
-#endif
         // ---- (4) finished walks: the rest of the segment (shading), next ray
         if (state == FINISH) {
             const bool alive = w.finish(p, pt, stack, tl);
@@ -1183,10 +1149,6 @@ DEV void trace_stepped(const KParams& p) {
         }
     }
     flush_tally<STATS>(tl, p.counters);
-#ifdef RB_FAST_PROFILE
-    // node passes, lanes in them, leaf passes, lanes in them, finish passes -> the five STATS counter slots
-    if (lane == 0u) for (int i = 0; i < 5; i++) atomicAdd(&p.counters[2 + i], prof[i]);
-#endif
 }
 
 template <bool STATS>

@@ -1720,6 +1720,33 @@ int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uin
 }
 
 // Debug hook for tests/test_gpu_math.py: device /, sqrt, normalize, u32->f32, min/max, dot.
+int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh_node* nodes, size_t n_nodes, const uint32_t* indices,
+                        size_t n_indices, uint64_t out6[6]) {
+    if (!tris || !nodes || !indices || !out6) return RB_ERR_NULL_ARGUMENT;
+    if (n_tris >= (1ull << 31) || n_nodes >= (1ull << 31) || n_indices >= (1ull << 31)) return RB_ERR_INVALID_BVH;
+    std::string why;
+    if (!rb::bvh_validate(nodes, static_cast<uint32_t>(n_nodes), rb::kStackDepth, why, nullptr)) return fail(nullptr, RB_ERR_INVALID_BVH, "%s", why.c_str());
+    rb::ChunkTree t;
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (!rb::chunk_tree_build(tris, static_cast<uint32_t>(n_tris), indices, static_cast<uint32_t>(n_indices), nodes,
+                              static_cast<uint32_t>(n_nodes), rb::kStackDepth, t))
+        return RB_OK;   // out6[0] == 0: this tree is left to another walk
+    if (!rb::chunk_tree_check(t, tris, static_cast<uint32_t>(n_tris), indices, static_cast<uint32_t>(n_indices), rb::kStackDepth, why))
+        return fail(nullptr, RB_ERR_INVALID_BVH, "chunk tree: %s", why.c_str());
+    uint64_t chunks = 0, unbounded = 0;
+    for (const rb::ChunkNode& c : t.nodes) {
+        chunks += ((c.lref != rb::kChunkNone && (c.lref & rb::kChunkLeaf)) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rref & rb::kChunkLeaf)) ? 1 : 0);
+        unbounded += ((c.lref != rb::kChunkNone && (c.lfac >> 16) == 0x7F80u) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rfac >> 16) == 0x7F80u) ? 1 : 0);
+    }
+    out6[0] = 1;
+    out6[1] = t.nodes.size();
+    out6[2] = t.pos_slot.size();
+    out6[3] = t.depth;
+    out6[4] = chunks;
+    out6[5] = unbounded;
+    return RB_OK;
+}
+
 int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_per_s) {
     if (!accesses_per_s) return RB_ERR_NULL_ARGUMENT;
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return RB_ERR_DEVICE;

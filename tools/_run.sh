@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-V=renderbaby_amd/variants
-{
-echo "== base"; WALKS=chunk timeout -k 10 200 python tools/chunk_probe.py speed c3 lamp c5 || exit 1
-for f in $V/lib_o2.so $V/lib_o4.so $V/lib_o16.so $V/lib_sp.so; do echo "== $f"; RB_LIBRARY_PATH=$f WALKS=chunk timeout -k 10 200 python tools/chunk_probe.py speed c3 lamp c5 || exit 1; done
-} 2>&1 | grep -v amdgpu | tee gpurun_out/hostexp.txt | awk '/^==/{v=$2} /k_trace_chunk/{printf "%-36s %-8s %-10s %8s Mseg/s diff %s nodes %s tris %s\n", v, $1, $2, $6, $15, $17, $19}'
+tools/refresh_profiles.sh r03 lamp_reference lamp_ownhost c5 c5_reference c5_owndevice iter
+echo "=== c5 at its real 4096 spp (one frame, for the frame checksum and the whole-frame rate)"
+timeout -k 10 300 python bench.py --workload c5 --steps 1 --warmup 0 --cpu-seconds 0 --no-stats --no-end-to-end > gpurun_out/c5_full.json 2> gpurun_out/c5_full.err; python3 -c "
+import json; d=json.loads(open('gpurun_out/c5_full.json').read().strip().splitlines()[-1]); print('c5 full', d['value'], d['ms_per_step'], d['verify'])"

@@ -170,6 +170,8 @@ def test_rccl_communicator_of_one_rank():
     e = Engine.new(rc)
     e.comm_init_rank(cid, 0, 1)
     assert np.array_equal(e.render(rc).pixels, _oracle.render(s)[2])
+    info = e.comm_info()   # ncclCommCount / ncclCommUserRank of the live communicator, and the root's share of the exchange
+    assert info["rccl_ranks"] == 1 and info["rccl_rank"] == 0 and info["gather_ms"] >= 0.0
     with pytest.raises(RenderError):
         e.comm_init_rank(cid, 1, 2)   # does not match the engine's shard geometry
     e.close()
@@ -180,6 +182,7 @@ def test_single_device_group_needs_no_communicator():
     rc = RenderConfig.from_scene(s)
     e = Engine.new(rc, devices=[0])
     assert np.array_equal(e.render(rc).pixels, _oracle.render(s)[2])
+    assert e.comm_info()["rccl_ranks"] == 0   # nothing goes through RCCL
     e.close()
 
 
@@ -291,3 +294,29 @@ def test_getters_from_another_thread_while_rendering():
         t.join()
     assert np.array_equal(f.pixels, _oracle.render(s)[2]) and set(seen) == {(64, 48)}
     e.close()
+
+
+def test_multi_device_handle_into_page_locked_memory_and_running_ahead():
+    # r03: the exchange and the read-back of a sharded engine run on its second stream; into page-locked memory the frame
+    # leaves by DMA on that stream; every part runs a pass ahead.  Frame k must still be the running average of samples 0..k.
+    from renderbaby_amd.engine import PinnedFrame
+    s = scenes.feature_scene(50, 37, 5, 4)
+    rc = RenderConfig.from_scene(s)
+    want = [_oracle.render(s, 0, k + 1)[2] for k in range(5)]
+    for ahead in (True, False):
+        e = Engine.new(rc, devices=[0, 0, 0], stripe_rows=4, gather_peer_copy=True, no_run_ahead=not ahead)
+        pf = PinnedFrame(50, 37)
+        cfg, keep = rc.to_c()
+        e._check(e._lib.rb_iter_begin(e._h, C.byref(cfg)))
+        del keep
+        k = 0
+        while e._lib.rb_iter_has_next(e._h):
+            e._check(e._lib.rb_iter_next(e._h, pf.array.ctypes.data))
+            assert np.array_equal(pf.array, want[k]), (ahead, k)
+            k += 1
+        assert k == 5
+        # a blocking render into the same page-locked buffer
+        e._check(e._lib.rb_render(e._h, pf.array.ctypes.data))
+        assert np.array_equal(pf.array, want[-1])
+        e.close()
+        pf.free()

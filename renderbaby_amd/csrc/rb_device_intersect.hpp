@@ -229,8 +229,8 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
     }
 }
 
-// Walk of the library's own tree over the same triangles (rb_bvh.cpp / rb_build.hip; the default for
-// multi-node meshes, RB_FLAG_REFERENCE_WALK selects the reference's walk instead): nearer child first, subtrees
+// Walk of the library's own tree over the same triangles (rb_bvh.cpp / rb_build.hip; RB_FLAG_FAST_BVH -- r02's default
+// for large meshes, since r03 the chunked walk of rb_kernels.hip is the default): nearer child first, subtrees
 // skipped when missed or entered beyond the best t.  It reproduces the reference walk's winner
 // (shader.wgsl:282-392) bit for bit -- DESIGN.md section 4 has the full argument:
 //  * candidates are evaluated with the reference's isect_triangle, so t, u, v are the same bits;

@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 // A lane whose stack runs empty is shaded (segment_finish) and starts its next segment or a new path while the others
 // keep walking, as in the other stepped kernels.
 #ifndef RB_CHUNK_WAVES
-#define RB_CHUNK_WAVES 5   // 96 registers, 6 of them spilled: 1691 / 2598 / 2564 M segments/s on C3 / lamp / C5 against 1610 / 2418 / 2490 at 4
+#define RB_CHUNK_WAVES 5   // 96 registers, a few of them spilled outside the hot loops: + 3..7 % over 4 waves per SIMD (profiles/r03_chunk_steps.txt); 6 spills too much
 #endif
 #ifndef RB_CHUNK_NODE_LANES
 #define RB_CHUNK_NODE_LANES 32   // keep stepping nodes while this many lanes are at one ...
@@ -634,10 +634,10 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)
 #endif
 #ifndef RB_CHUNK_SP
-#define RB_CHUNK_SP 0
+#define RB_CHUNK_SP 0            // Sp of a child box: 0 = Euclidean distance to its farthest corner, 1 = by the largest component (3 % slower: wider margins)
 #endif
 #ifndef RB_CHUNK_CONT
-#define RB_CHUNK_CONT 1
+#define RB_CHUNK_CONT 1          // 1 = the bound of L^2 / |a^| from the ray's own cone bound of |cos|, 0 = the fixed c0 of section 4.1 (1-2 % slower)
 #endif
 #ifndef RB_CHUNK_DEFER
 #define RB_CHUNK_DEFER 1         // a lane that reaches a chunk puts it aside and walks on to its next one before it waits
@@ -1470,9 +1470,10 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
     } else {
         const uint64_t tiles = (uint64_t)((p.u.width + 7u) / 8u) * ((p.local_rows + 7u) / 8u);
         const uint64_t items = tiles * 64u * p.n_passes * p.samples_per_pass;
-        // which trace kernel: multi-node tree walked exactly (from LDS when the mesh fits next to the
-        // stacks: one 1024-thread block per CU, measured faster than three 256-thread blocks with a copy
-        // each), the opt-in walk, the sphere tree, or the plain kernel (single-node tree, <= 64 spheres)
+        // which trace kernel, by what the runtime has prepared: the chunked walk (multi-node trees, the default), the
+        // library's own tree (RB_FLAG_FAST_BVH), the reference-order walk (RB_FLAG_REFERENCE_WALK; from LDS when the
+        // mesh fits next to the stacks: one 1024-thread block per CU, measured faster than three 256-thread blocks
+        // with a copy each), the sphere tree, or the plain kernel (single-node tree, <= 64 spheres)
         enum Variant { PLAIN, BVH, BVH_LDS, FAST, SPH, CHUNK };
         const bool multi = p.u.bvh_node_count > 1u && !p.no_leaf_stepping;
         const size_t scene_lds = (size_t)p.u.bvh_node_count * 48u + (size_t)p.index_len * 48u;

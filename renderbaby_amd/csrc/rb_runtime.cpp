@@ -1667,7 +1667,7 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris, rb_bvh_node* nodes_
     return RB_OK;
 }
 
-const char* rb_version(void) { return "renderbaby-hip 0.2 (gfx950)"; }
+const char* rb_version(void) { return "renderbaby-hip 0.3 (gfx950)"; }
 
 const char* rb_last_kernel_name(const rb_engine* e) {
     if (!e) return "";

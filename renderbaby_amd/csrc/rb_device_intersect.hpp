@@ -256,6 +256,8 @@ DEV void test_pair(const v4f a0, const v4f b0, const v4f c0, bool ok0, const v4f
 // if |a^| >= 1e-6), the point X = o + t^ d of an ACCEPTED hit satisfies (u = 2^-24, first order, every rounding of
 // shader.wgsl:248-280 in the no-FMA f32 arithmetic of the contract)
 //     dist_inf(X, box(triangle k)) <= 26 u (|s| + L) L^2 / |a_k|  +  7.5 u (|s| + 2 L)
+// (r03's sharper sum, second order included: (21.4 |s| + 9.1 L) u L^2 / |a_k|, of which 11.2 |s| + 4.6 L across the ray and
+// 10.2 |s| + 4.6 L along it -- k_trace_chunk uses the two parts separately, this walk keeps the round figure)
 // as long as 5.42 u L^2 / |a^| <= 0.05.  With |cos| >= c0: L^2 / |a_k| <= (max_k L_k^2 / N_k) / c0, a per-child
 // constant FA (stored in the node's pad words with the 0.95 that bounds |a^| >= 0.95 |a|; +inf = always enter,
 // beyond 1.5e5 where no bound is claimed or for a triangle with N = 0); |s| + 2 L <= Sp = (distance from o to the

@@ -16,9 +16,11 @@ _spec.loader.exec_module(mc)
 @pytest.mark.parametrize("regime", ["floor", "grazing", "steep"])
 def test_accepted_hits_stay_within_the_margin(regime):
     rng = np.random.default_rng({"floor": 1, "grazing": 2, "steep": 3}[regime])
-    accepted, worst, _, case = mc.check(rng, 600_000, regime)
+    accepted, worst, _, case, across, along = mc.check(rng, 600_000, regime)
     assert accepted > 5_000                      # the sampler really produces accepted hits in this regime
     assert worst <= 1.0, case                    # a counterexample to the bound would be a counterexample to both walks
+    # the chunked walk's two parts: the exact plane point against the box, the reported t against the exact one
+    assert across <= 1.0 and along <= 1.0, (across, along)
 
 
 def test_the_emulated_triangle_test_is_the_oracles():

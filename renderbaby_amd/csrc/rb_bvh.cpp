@@ -673,7 +673,8 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
 namespace {
 struct ChunkInfo {
     uint32_t ref = kChunkNone;
-    double cap = 0.0, fa = 0.0;
+    double cap = 0.0, fa = 0.0;      // with G = max(|e1| |e2|, L^2 / 4) (chunk_g)
+    double cap_l = 0.0, fa_l = 0.0;  // with L^2: what is stored where a triangle below is beyond the range the bounds are claimed for
     DCone cone;
     uint32_t depth = 0;   // internal nodes on the longest path below (= stack entries the walk may need)
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};   // tight bounds of the triangles below
@@ -681,7 +682,7 @@ struct ChunkInfo {
 struct ChunkItem {
     uint32_t slot, rank;
     float mn[3], mx[3];
-    double cap, fa;
+    double cap, fa, cap_l, fa_l;
     double n[3];
     bool has_normal;
 };
@@ -729,6 +730,12 @@ void encode_cone(const DCone& c, float o[4]) {
     o[2] = static_cast<float>(c.c[2] * cos_a);
     o[3] = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
 }
+// E7's leading terms carry |e1| |e2| where r02 wrote L^2 = max(|e1|, |e2|)^2: the chunked walk stores its bounds with
+// G = |e1| |e2| in place of L^2.  The bounds are claimed while 5.42 u L^2 / |a^| <= 0.05 -- with L^2.  An accepted hit has
+// |a^| >= 1e-6, so that holds for every triangle with L^2 / 1e-6 <= 1.5e5 whatever the ray; a child slot with a larger
+// triangle below it stores +inf as its floor bound and its |cos| >= c0 bound with L^2, as r02 did, so that the kernel's test
+// "F <= 1.5e5" is the proviso itself there (pack_fac).
+double chunk_g(double l1sq, double l2sq) { return std::sqrt(l1sq) * std::sqrt(l2sq) * (1.0 + 1e-12); }
 // v >= 0 as bf16, rounded up; beyond 1.5e5 (where the bound is not claimed) +inf
 uint32_t bf16_up(double v) {
     if (!(v <= 1.5e5)) return 0x7F80u;
@@ -738,7 +745,10 @@ uint32_t bf16_up(double v) {
     std::memcpy(&b, &f, 4);
     return (b >> 16) + ((b & 0xFFFFu) ? 1u : 0u);
 }
-uint32_t pack_fac(const ChunkInfo& i) { return (bf16_up(i.cap * (1.0 + 1e-6)) << 16) | bf16_up(i.fa); }
+uint32_t pack_fac(const ChunkInfo& i) {
+    if (!(i.cap_l * (1.0 + 1e-6) <= 1.5e5)) return (0x7F80u << 16) | bf16_up(i.fa_l);
+    return (bf16_up(i.cap * (1.0 + 1e-6)) << 16) | bf16_up(i.fa);
+}
 
 struct ChunkBuilder {
     ChunkTree& out;
@@ -776,6 +786,8 @@ struct ChunkBuilder {
                 out.pos_rank.push_back(items[i].rank);
                 r.cap = std::max(r.cap, items[i].cap);
                 r.fa = std::max(r.fa, items[i].fa);
+                r.cap_l = std::max(r.cap_l, items[i].cap_l);
+                r.fa_l = std::max(r.fa_l, items[i].fa_l);
             }
             tight(lo, hi, r.mn, r.mx);
             r.cone = cone_of(&items[lo], count);
@@ -811,6 +823,8 @@ struct ChunkBuilder {
         out.nodes.push_back(n);
         r.cap = std::max(l.cap, rr.cap);
         r.fa = std::max(l.fa, rr.fa);
+        r.cap_l = std::max(l.cap_l, rr.cap_l);
+        r.fa_l = std::max(l.fa_l, rr.fa_l);
         r.cone = merge_cones(l.cone, rr.cone);
         r.depth = 1 + std::max(l.depth, rr.depth);
         tight(lo, hi, r.mn, r.mx);
@@ -888,9 +902,12 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                     ll += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
                     l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
                 }
-                const TriBound b = tri_bound(t, 0.0f);   // threshold 0: every triangle keeps its |cos| >= c0 bound
-                it.cap = std::max(ll, l2) * 1e6 * (1.0 + 1e-5);
-                it.fa = b.f;
+                const TriBound b = tri_bound(t, 0.0f);   // threshold 0: every triangle keeps its |cos| >= c0 bound (of L^2 / |a|)
+                const double g = chunk_g(ll, l2), lmax = std::max(ll, l2);
+                it.cap = g * 1e6 * (1.0 + 1e-5);
+                it.fa = (b.has_normal && lmax > 0.0) ? double(b.f) * (g / lmax) * (1.0 + 1e-9) : double(b.f);   // no normal: +inf; a point: 0
+                it.cap_l = lmax * 1e6 * (1.0 + 1e-5);
+                it.fa_l = b.f;
                 it.has_normal = b.has_normal;
                 for (int a = 0; a < 3; ++a) it.n[a] = b.n[a];
                 items.push_back(it);
@@ -912,6 +929,8 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             out.nodes.push_back(c);
             r.cap = std::max(l.cap, rr.cap);
             r.fa = std::max(l.fa, rr.fa);
+            r.cap_l = std::max(l.cap_l, rr.cap_l);
+            r.fa_l = std::max(l.fa_l, rr.fa_l);
             r.cone = merge_cones(l.ref == kChunkNone ? empty_cone() : l.cone, rr.ref == kChunkNone ? empty_cone() : rr.cone);
             r.depth = 1 + std::max(l.depth, rr.depth);
             for (int a = 0; a < 3; ++a) {
@@ -964,7 +983,7 @@ bool chunk_tree_check(const ChunkTree& t, const rb_gpu_triangle* tris, uint32_t 
                     l1 += double(g.v1[a] - g.v0[a]) * double(g.v1[a] - g.v0[a]);
                     l2 += double(g.v2[a] - g.v0[a]) * double(g.v2[a] - g.v0[a]);
                 }
-                out.cap = std::max(out.cap, std::max(l1, l2) * 1e6);
+                out.cap = std::max(out.cap, chunk_g(l1, l2) * 1e6);
             }
             return true;
         }

@@ -654,11 +654,14 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 // of the hit's error (21.4 |s| + 9.1 L) u L^2 / |a|, (11.2 |s| + 4.6 L) is how far the exact plane
 // point Q* = o + t* d can be from the triangle's box -- that part inflates the box --, (10.2 |s| + 4.6 L) is |t^ - t*|, which
 // only moves the hit along the ray.  4 u of kChunkKS are for the slab arithmetic done on the uninflated box (chunk_child).
+// The stored bounds are of G / |a^| with G = |e1| |e2| where r02 had L^2 (E7's leading terms carry |e1| |e2|); the proviso of the
+// bounds, 5.42 u L^2 / |a^| <= 0.05, is the host's business where it can be (rb_bvh.cpp pack_fac) and this test elsewhere.
+constexpr float kChunkFMax = 1.5e5f;
 constexpr float kChunkKS = 24.0f * 5.9604645e-8f * 1.01f;
 #if RB_CHUNK_SPLIT
 constexpr float kChunkKP = 12.0f * 5.9604645e-8f * 1.01f;   // across
 constexpr float kChunkKT = 11.0f * 5.9604645e-8f * 1.01f;   // along
-constexpr float kChunkKD = 12.0f * 5.9604645e-8f * 1.01f;   // along, the relative part: 4 u t^, |d| = 1 +- 4 u, in units of Sp
+constexpr float kChunkKD = 16.0f * 5.9604645e-8f * 1.01f;   // along, the relative part: 4 u t^ (t^ |d| <= |s| + 2.1 L), |d| = 1 +- 4 u, in units of Sp
 #else
 constexpr float kChunkKF = 27.0f * 5.9604645e-8f * 1.01f;   // FastWalk's margin
 #endif
@@ -697,20 +700,21 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     // the determinant floor if it may graze a triangle there
     const float f = cone_admits_grazing(d, cone) ? __uint_as_float(fac & 0xFFFF0000u) : __uint_as_float(fac << 16);
 #endif
-    // Sp >= |o - v0| + 2 L for every triangle below: farthest corner (v_sqrt_f32 is within 1 ulp) + box extents
+    // Sp >= |o - v0| + L / 2 for every triangle below (E7's L terms are less than half its |s| terms): farthest corner
+    // (v_sqrt_f32 is within 1 ulp) + half the box's extents
     const float mx = max_abs(a.x, b.x), my = max_abs(a.y, b.y), mz = max_abs(a.z, b.z);
 #if RB_CHUNK_SP == 0
     const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz))) +
-                      2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+                      0.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
 #else   // the corner's distance by its largest component: within sqrt(3), three instructions instead of eight
-    const float sp_ = 1.7321f * fmaxf(fmaxf(mx, my), mz) + 2.0f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
+    const float sp_ = 1.7321f * fmaxf(fmaxf(mx, my), mz) + 0.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
 #endif
     const float ix = fabsf(inv.x), iy = fabsf(inv.y), iz = fabsf(inv.z);
 #if RB_CHUNK_SPLIT
     // Q* = o + t* d, the exact plane point of an accepted hit, lies on the ray within mm of the triangle's box, so the ray's
     // line passes the box inflated by mm at parameters [tn, tf] that hold t*; what is reported, t^, is within dt of t*, has to
     // be positive and, for the winner, no larger than the best t so far
-    const bool fin = f <= 1.5e5f;                                            // NaN -> always enter
+    const bool fin = f <= kChunkFMax;                                        // NaN -> always enter
     const float mm = fin ? sp_ * __builtin_fmaf(kChunkKP, f, kChunkKS) : 1e30f;
     const float dt = fin ? sp_ * __builtin_fmaf(kChunkKT, f, kChunkKD) : 1e30f;
     const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
@@ -718,7 +722,8 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     order = tn;
     return !(tf < tn) && !(tf < -dt) && !(tn - dt > best_t);
 #else
-    const float mm = (f <= 1.5e5f) ? sp_ * __builtin_fmaf(kChunkKF, f, kChunkKS) : 1e30f;   // NaN -> 1e30
+    const float sp0 = sp_ + 1.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));               // section 4.1's Sp: + 2 extents
+    const float mm = (f <= kChunkFMax) ? sp0 * __builtin_fmaf(kChunkKF, f, kChunkKS) : 1e30f;   // NaN -> 1e30
     const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
     const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fx), __builtin_fmaf(mm, iy, fy)), __builtin_fmaf(mm, iz, fz));
     order = tn;

@@ -94,3 +94,19 @@ def test_fuzzed_geometry():
         built += r["built"]
         assert r["built"] == 0 or r["positions"] == len(s.bvh_triangles), seed
     assert built > 100
+
+
+def test_a_sliver_beyond_the_claimed_range_is_always_entered():
+    # The stored bounds carry |e1| |e2|, the range they are claimed for is about L^2: a 0.5 x 0.001 sliver has
+    # |e1| |e2| / 1e-6 = 500 but L^2 / 1e-6 = 2.5e5 > 1.5e5, so every child slot above it must carry +inf as its floor bound.
+    base = scenes.mesh_scene(70, 70, 32, 24, 1, 3, seed=70)   # 0.16-unit cells: inside the range
+    gp = _load("tests/test_gpu_parity.py", "gpu_parity_helpers2")
+    nodes, indices = gp._py_tree(base.bvh_triangles, 128, 0)
+    r0 = _check(base.bvh_triangles, nodes, indices)
+    tris = base.bvh_triangles.copy()
+    v0 = tris["v0"][5][:3].copy()
+    tris["v1"][5][:3] = v0 + np.float32([0.5, 0.0, 0.0])
+    tris["v2"][5][:3] = v0 + np.float32([0.0, 0.001, 0.0])
+    nodes, indices = gp._py_tree(tris, 128, 0)
+    r = _check(tris, nodes, indices)
+    assert r["built"] == 1 and r["unbounded"] > r0["unbounded"]

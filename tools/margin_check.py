@@ -112,8 +112,8 @@ def check(rng, n, regime):
     margin = Sp * (27.0 * U * F + 24.0 * U)
     ratio = dist / margin
     # the same bound in the two parts the chunked walk uses: the exact plane point Q* = o + t* d of
-    # the f32 inputs (double precision: 2^-53 against the 2^-24 under test) within Sp (12 u F + 24 u) of the box, and
-    # |t^ - t*| <= Sp (11 u F + 12 u)
+    # the f32 inputs (double precision: 2^-53 against the 2^-24 under test) within S (12 u F' + 24 u) of the box, and
+    # |t^ - t*| <= S (11 u F' + 16 u), with S = |o - v0| + L / 2 and F' = F with |e1| |e2| in place of L^2
     h = (d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0])
     ax = sum(e1[i] * h[i] for i in range(3))
     sv = [o[i] - v0[i] for i in range(3)]
@@ -124,8 +124,11 @@ def check(rng, n, regime):
     for i in range(3):
         lo, hi = np.minimum(np.minimum(v0[i], v1[i]), v2[i]), np.maximum(np.maximum(v0[i], v1[i]), v2[i])
         dq = np.maximum(dq, np.maximum(lo - Q[i], Q[i] - hi))
-    across = float((np.maximum(dq, 0.0) / (Sp * (12.0 * U * F + 24.0 * U))).max())
-    along = float((np.abs(t - tx) / (Sp * (11.0 * U * F + 12.0 * U))).max())
+    A = np.sqrt(sum(e1[i] ** 2 for i in range(3)) * sum(e2[i] ** 2 for i in range(3)))    # |e1| |e2| in place of L^2
+    Fa = np.minimum(A / 1e-6, (A / np.maximum(N, 1e-300)) / np.maximum(0.95 * cosn, 1e-300))
+    Sh = s + 0.5 * np.sqrt(L2)
+    across = float((np.maximum(dq, 0.0) / (Sh * (12.0 * U * Fa + 24.0 * U))).max())
+    along = float((np.abs(t - tx) / (Sh * (11.0 * U * Fa + 16.0 * U))).max())
     k = int(np.argmax(ratio))
     worst = dict(ratio=float(ratio[k]), dist=float(dist[k]), margin=float(margin[k]), a=float(a[k]), cos=float(cosn[k]),
                  L=float(np.sqrt(L2[k])), s=float(s[k]), F=float(F[k]), t=float(t[k]))
@@ -138,7 +141,7 @@ def main():
     per = 2_000_000
     print(f"# margin_check: {millions:g} M rays per regime, numpy float32 = the shader's single IEEE operations; seed 20241004")
     print("# bound: dist_inf(o + t^ d, box(triangle)) <= (|o - v0| + 2 L) (27 u F + 24 u),  F = min(L^2 / 1e-6, (L^2 / N) / (0.95 |cos|))")
-    print("# in two parts (the chunked walk): dist_inf(o + t* d, box) <= Sp (12 u F + 24 u) and |t^ - t*| <= Sp (11 u F + 12 u), t* = the exact plane point's")
+    print("# in two parts (the chunked walk): dist_inf(o + t* d, box) <= S (12 u F' + 24 u) and |t^ - t*| <= S (11 u F' + 16 u); t* = the exact plane point's,\n# S = |o - v0| + L / 2, F' = F with |e1| |e2| in place of L^2")
     t0 = time.time()
     overall = 0.0
     for regime in ("floor", "grazing", "steep"):
@@ -152,7 +155,7 @@ def main():
                 mx, worst = m, w
         overall = max(overall, mx, across, along)
         print(f"{regime:8s}: {acc:10d} accepted hits of {int(millions * 1e6)} rays; largest dist / margin = {mx:.4f}; 99.9th percentile <= {p999:.4f}")
-        print(f"          in two parts: plane point to box / Sp (12 u F + 24 u) = {across:.4f}; |t^ - t*| / Sp (11 u F + 12 u) = {along:.4f}")
+        print(f"          in two parts: plane point to box / S (12 u F' + 24 u) = {across:.4f}; |t^ - t*| / S (11 u F' + 16 u) = {along:.4f}")
         if worst:
             print("          worst case: " + ", ".join(f"{k} {v:.4g}" for k, v in worst.items()))
     print(f"# largest ratio overall {overall:.4f} ({'within the bound' if overall <= 1.0 else 'COUNTEREXAMPLE'}); {time.time() - t0:.0f} s")

@@ -21,6 +21,7 @@ from tests import _oracle
 def random_scene(seed):
     rng = np.random.default_rng(seed)
     big = bool(os.environ.get("FUZZ_BIG"))   # larger frames / more samples: several queue reservations per wave
+    slivers = bool(os.environ.get("FUZZ_SLIVERS"))   # a different stream of scenes: mid-sized thin triangles, grazed more often
     w, h = int(rng.integers(1, 300 if big else 28)), int(rng.integers(1, 200 if big else 20))
     spp, depth = int(rng.integers(1, 10 if big else 4)), int(rng.integers(0, 9))
     f = lambda lo, hi, n=None: np.float32(rng.uniform(lo, hi)) if n is None else rng.uniform(lo, hi, n).astype(np.float32)
@@ -73,6 +74,12 @@ def random_scene(seed):
                     v = [c + f(-1e-3, 1e-3, 3) for _ in range(3)]
                 elif kind < 0.4:    # axis-aligned in a plane
                     v = [c + np.array([0, a, b], np.float32) for a, b in ((0, 0), (1, 0), (0, 1))]
+                elif slivers:       # mid-sized, thin: |e1| |e2| far below L^2, inside the range the floor margin is claimed for
+                    e = f(-1, 1, 3); e = e / max(float(np.linalg.norm(e)), 1e-6) * np.float32(10.0 ** rng.uniform(-1.7, -0.45))
+                    w_ = f(-1, 1, 3) * np.float32(10.0 ** rng.uniform(-3.5, -1.0))
+                    v = [c, c + w_, c + e] if rng.random() < 0.5 else [c, c + e, c + e * f(0.0, 1.0) + w_]   # a short edge at v0, or a flat apex
+                    k = int(rng.integers(0, 3))
+                    v = v[k:] + v[:k]
                 else:
                     v = [c + f(-0.7, 0.7, 3) for _ in range(3)]
                 tris.append(tuple(tuple(map(float, p)) for p in v))
@@ -83,7 +90,7 @@ def random_scene(seed):
                                 emissive=f(0, 5, 3) * (rng.random() < 0.3), texture_index=0 if (use_tex and g == 0) else -1)
             groups.append((m, tris)); uv_groups.append(uvs)
     sc = scenes._finish(f"fuzz{seed}", u, sp, lights, groups, uv_groups, tex)
-    if nt and rng.random() < 0.25:
+    if nt and rng.random() < (0.6 if slivers else 0.25):
         graze(sc, rng)
     return sc
 

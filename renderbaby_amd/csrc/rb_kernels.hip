@@ -253,6 +253,15 @@ struct ColorRing {
 #ifndef RB_TRACE_WAVES_BIG
 #define RB_TRACE_WAVES_BIG 8
 #endif
+#ifndef RB_XCD_BANDS
+#define RB_XCD_BANDS 1
+#endif
+struct QueueInit {
+    uint32_t start[kQueueGroups];
+};
+__global__ void k_queue_init(uint32_t* queue, QueueInit qi) {
+    if (threadIdx.x < kQueueGroups) queue[threadIdx.x * kQueueStride] = qi.start[threadIdx.x];
+}
 constexpr uint64_t kTraceManyItems = 3ull << 23;  // launches from here on take k_trace's 8-wave instantiation
 
 // The (pixel, sample) work queue of the stream kernels, one instance per wavefront.  The global
@@ -263,20 +272,62 @@ constexpr uint64_t kTraceManyItems = 3ull << 23;  // launches from here on take 
 struct ItemQueue {
     uint32_t loc_next = 0, loc_end = 0;  // this wave's reserved item range (wave-uniform)
     uint32_t batch;                      // items per reservation
+    uint32_t grp = 0, tried = 0;         // the band this wave draws from, and how many bands it has found empty
     bool exhausted = false;
     // The first reservation is the wave's own: wave w starts on items [w * batch, (w + 1) * batch) and the queue word
     // starts at waves * batch (launch_render), so a launch does not begin with every wave queueing for the one word
     // (4096-8192 atomics at ~90 M/s: up to 45-90 us before the last wave had work).
-    DEV ItemQueue(uint32_t batch_, uint32_t total_items) : batch(batch_) {
-        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        const uint64_t first = (uint64_t)wave * batch_;
-        if (first < total_items) {
-            loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
-            loc_end = (total_items - loc_next < batch_) ? total_items : loc_next + batch_;
+    // With p.queue_groups = 8 the items are cut into 8 bands (of tile rows), one queue word each: the blocks that share an XCD
+    // (blockIdx % 8, MI355X_MICROARCH.md: blocks are dealt round-robin over the XCDs; speed only) work through one band, so
+    // that an XCD's L2 holds the part of the tree its band looks at, and move on to the other bands when theirs is done.
+    DEV ItemQueue(const KParams& p, uint32_t total_items) : batch(p.queue_batch) {
+        const uint32_t wpb = blockDim.x >> 6;
+        if (p.queue_groups <= 1u) {
+            const uint64_t first = (uint64_t)(blockIdx.x * wpb + (threadIdx.x >> 6)) * batch;
+            if (first < total_items) {
+                loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
+                loc_end = (total_items - loc_next < batch) ? total_items : loc_next + batch;
+            }
+        } else {
+            grp = blockIdx.x % p.queue_groups;
+            const uint64_t lo = (uint64_t)grp * p.queue_region, hi = lo + p.queue_region < total_items ? lo + p.queue_region : total_items;
+            const uint64_t first = lo + (uint64_t)((blockIdx.x / p.queue_groups) * wpb + (threadIdx.x >> 6)) * batch;
+            if (first < hi) {
+                loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
+                loc_end = (hi - first < batch) ? (uint32_t)hi : loc_next + batch;
+            }
         }
     }
 
     DEV bool drained() const { return exhausted && loc_next == loc_end; }
+
+    // a new reservation; false when there is nothing left anywhere
+    DEV bool reserve(const KParams& p, uint32_t lane, uint32_t total_items) {
+        if (p.queue_groups <= 1u) {
+            uint32_t b = 0;
+            if (lane == 0u) b = atomicAdd(p.queue, batch);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b >= total_items) return false;
+            loc_next = b;
+            loc_end = (total_items - b < batch) ? total_items : b + batch;
+            return true;
+        }
+        while (tried < p.queue_groups) {
+            uint32_t b = 0;
+            if (lane == 0u) b = atomicAdd(p.queue + grp * kQueueStride, batch);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            const uint64_t hi64 = (uint64_t)(grp + 1u) * p.queue_region;
+            const uint32_t hi = hi64 < total_items ? (uint32_t)hi64 : total_items;
+            if (b < hi) {
+                loc_next = b;
+                loc_end = (hi - b < batch) ? hi : b + batch;
+                return true;
+            }
+            grp = (grp + 1u == p.queue_groups) ? 0u : grp + 1u;   // this band is done for good: the words only grow
+            tried++;
+        }
+        return false;
+    }
 
     template <class IsIdle, class OnItem>
     DEV void refill(const KParams& p, uint32_t lane, uint32_t total_items, uint32_t S, uint32_t tiles_x,
@@ -285,15 +336,10 @@ struct ItemQueue {
         for (int round = 0; round < 2 && idle != 0ull; round++) {
             if (loc_next == loc_end) {
                 if (exhausted) break;
-                uint32_t b = 0;
-                if (lane == 0u) b = atomicAdd(p.queue, batch);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= total_items) {
+                if (!reserve(p, lane, total_items)) {
                     exhausted = true;
                     break;
                 }
-                loc_next = b;
-                loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
             const ItemRows rows = item_rows(p, loc_next, S, tiles_x, sample_base);
             const uint32_t avail = loc_end - loc_next;
@@ -495,7 +541,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0;
-    ItemQueue iq(p.queue_batch, total_items);
+    ItemQueue iq(p, total_items);
     Path pt;
     pt.depth = 0;
     TriHit th;
@@ -786,7 +832,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
     uint32_t state = IDLE;
     uint32_t item = 0, cur = 0;
     [[maybe_unused]] uint32_t pend = kChunkNone;   // RB_CHUNK_DEFER: the chunk this lane has put aside (cur == kChunkNone: nothing else left to walk)
-    ItemQueue iq(p.queue_batch, total_items);
+    ItemQueue iq(p, total_items);
     Path pt;
     pt.depth = 0;
     f3 inv = mk(0, 0, 0);
@@ -1092,7 +1138,7 @@ DEV void trace_stepped(const KParams& p) {
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0;
-    ItemQueue iq(p.queue_batch, total_items);
+    ItemQueue iq(p, total_items);
     Path pt;
     pt.depth = 0;
     Walk w;
@@ -1548,9 +1594,27 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
             q.magic_S = S > 1u ? (uint32_t)((1ull << 32) / S) : 0xFFFFFFFFu;
             q.magic_tiles_x = tiles_x > 1u ? (uint32_t)((1ull << 32) / tiles_x) : 0xFFFFFFFFu;
         }
-        // the queue starts behind the waves' own first reservations (ItemQueue)
-        const uint64_t queue_start = waves * batch;   // <= 8192 waves * 4096 items
-        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), (int)(uint32_t)queue_start, 1, stream);
+        // the queue starts behind the waves' own first reservations (ItemQueue); the walks of trees and sphere sets get one band of
+        // items and one queue word per group of blocks that share an XCD
+        hipError_t e = hipSuccess;
+        const bool banded = v != PLAIN && RB_XCD_BANDS && li.grid >= kQueueGroups && items >= 64ull * batch * kQueueGroups;
+        if (banded) {
+            q.queue_groups = kQueueGroups;
+            const uint64_t per = (items + kQueueGroups - 1u) / kQueueGroups;
+            q.queue_region = (uint32_t)(((per + batch - 1u) / batch) * batch);
+            QueueInit qi;
+            for (uint32_t g = 0; g < kQueueGroups; g++) {
+                const uint64_t blocks_g = (li.grid + kQueueGroups - 1u - g) / kQueueGroups;
+                qi.start[g] = (uint32_t)std::min<uint64_t>((uint64_t)g * q.queue_region + blocks_g * (li.block / 64u) * batch, 0xFFFF0000ull);
+            }
+            hipLaunchKernelGGL(k_queue_init, dim3(1), dim3(64), 0, stream, p.queue, qi);
+            e = hipGetLastError();
+        } else {
+            q.queue_groups = 1u;
+            q.queue_region = 0u;
+            const uint64_t queue_start = waves * batch;   // <= 8192 waves * 4096 items
+            e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), (int)(uint32_t)queue_start, 1, stream);
+        }
         if (e != hipSuccess) return (int)e;
         const dim3 grid(li.grid), block(li.block);
         switch (v) {

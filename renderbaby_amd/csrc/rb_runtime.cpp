@@ -1087,7 +1087,7 @@ rb_engine* create_single(const rb_config* cfg, const rb_options& opt) {
     for (FrameSlot& s : e->slot)
         if ((st = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", st);
     if ((st = e->counters.resize(rb::C_COUNT)) != hipSuccess) return bail("hipMalloc(counters)", st);
-    if ((st = e->queue.resize(4)) != hipSuccess) return bail("hipMalloc(queue)", st);
+    if ((st = e->queue.resize(rb::kQueueWords)) != hipSuccess) return bail("hipMalloc(queue)", st);
     if ((st = hipMemsetAsync(e->counters.ptr, 0, sizeof(unsigned long long) * rb::C_COUNT, e->stream)) != hipSuccess)
         return bail("hipMemset(counters)", st);
     // sRGB -> linear table for sample_texture's pow(c, 2.2) (shader.wgsl:185-190)

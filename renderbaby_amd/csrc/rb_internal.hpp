@@ -253,8 +253,8 @@ struct KParams {
     uint32_t stack_depth;          // LDS traversal-stack entries per lane (0 for single-node trees)
     uint32_t blocks_per_cu;        // persistent grid density (0 = default)
     uint32_t queue_batch;          // items a wave reserves per global atomic (RB_KERNEL_STREAM)
-    uint32_t queue_groups;         // 1, or 8: one queue word per group of blocks that share an XCD (blockIdx % 8), each with its own band of items (set by launch_render)
-    uint32_t queue_region;         // items per band (a multiple of queue_batch)
+    uint32_t queue_groups;         // 1, or 8: one queue word per group of blocks that share an XCD (blockIdx % 8), each with its own stripes of items (set by launch_render)
+    uint32_t queue_region;         // items per stripe (a multiple of queue_batch); stripe k belongs to band k % queue_groups
     uint32_t no_leaf_stepping;     // RB_KERNEL_STREAM: 1 = per-segment traversal even for multi-node trees
     uint32_t lds_mode;             // LDS staging of small meshes: 0 = when it fits, 1 = never
     uint32_t magic_S, magic_tiles_x; // floor(2^32 / d) for the item decode of the stream kernels (set by launch_render)

@@ -277,9 +277,12 @@ struct ItemQueue {
     // The first reservation is the wave's own: wave w starts on items [w * batch, (w + 1) * batch) and the queue word
     // starts at waves * batch (launch_render), so a launch does not begin with every wave queueing for the one word
     // (4096-8192 atomics at ~90 M/s: up to 45-90 us before the last wave had work).
-    // With p.queue_groups = 8 the items are cut into 8 bands (of tile rows), one queue word each: the blocks that share an XCD
-    // (blockIdx % 8, MI355X_MICROARCH.md: blocks are dealt round-robin over the XCDs; speed only) work through one band, so
-    // that an XCD's L2 holds the part of the tree its band looks at, and move on to the other bands when theirs is done.
+    // With p.queue_groups = 8 the items are cut into stripes of p.queue_region items (a few tile rows) and dealt to 8 bands, stripe
+    // k to band k % 8, one queue word per band: the blocks that share an XCD (blockIdx % 8, MI355X_MICROARCH.md: blocks are dealt
+    // round-robin over the XCDs; speed only) work through one band, so that an XCD's L2 holds the part of the tree its stripe looks
+    // at, and move on to the other bands when theirs is done.  Interleaved rather than 8 contiguous bands: a frame whose top costs
+    // less than its bottom would leave the chip unevenly loaded until the stealing starts.  A band's queue word counts in the band's
+    // own index space (stripe after stripe); band_item turns that into the item.
     DEV ItemQueue(const KParams& p, uint32_t total_items) : batch(p.queue_batch) {
         const uint32_t wpb = blockDim.x >> 6;
         if (p.queue_groups <= 1u) {
@@ -290,16 +293,27 @@ struct ItemQueue {
             }
         } else {
             grp = blockIdx.x % p.queue_groups;
-            const uint64_t lo = (uint64_t)grp * p.queue_region, hi = lo + p.queue_region < total_items ? lo + p.queue_region : total_items;
-            const uint64_t first = lo + (uint64_t)((blockIdx.x / p.queue_groups) * wpb + (threadIdx.x >> 6)) * batch;
-            if (first < hi) {
-                loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
-                loc_end = (hi - first < batch) ? (uint32_t)hi : loc_next + batch;
+            const uint64_t first = (uint64_t)((blockIdx.x / p.queue_groups) * wpb + (threadIdx.x >> 6)) * batch;
+            uint32_t it = 0;
+            if (first < 0xFFFFFFFFull && band_item(p, grp, (uint32_t)first, total_items, it)) {
+                loc_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+                loc_end = (total_items - loc_next < batch) ? total_items : loc_next + batch;
             }
         }
     }
 
     DEV bool drained() const { return exhausted && loc_next == loc_end; }
+
+    // position `local` of band g -> item; false beyond the band's last item.  Stripes are whole multiples of the batch, so a
+    // reservation never straddles two.
+    DEV static bool band_item(const KParams& p, uint32_t g, uint32_t local, uint32_t total_items, uint32_t& item) {
+        const uint32_t stripe = p.queue_region;
+        const uint32_t k = local / stripe;
+        const uint64_t it = ((uint64_t)k * p.queue_groups + g) * stripe + (local - k * stripe);
+        if (it >= total_items) return false;
+        item = (uint32_t)it;
+        return true;
+    }
 
     // a new reservation; false when there is nothing left anywhere
     DEV bool reserve(const KParams& p, uint32_t lane, uint32_t total_items) {
@@ -316,11 +330,10 @@ struct ItemQueue {
             uint32_t b = 0;
             if (lane == 0u) b = atomicAdd(p.queue + grp * kQueueStride, batch);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            const uint64_t hi64 = (uint64_t)(grp + 1u) * p.queue_region;
-            const uint32_t hi = hi64 < total_items ? (uint32_t)hi64 : total_items;
-            if (b < hi) {
-                loc_next = b;
-                loc_end = (hi - b < batch) ? hi : b + batch;
+            uint32_t it = 0;
+            if (band_item(p, grp, b, total_items, it)) {
+                loc_next = it;
+                loc_end = (total_items - it < batch) ? total_items : it + batch;
                 return true;
             }
             grp = (grp + 1u == p.queue_groups) ? 0u : grp + 1u;   // this band is done for good: the words only grow
@@ -1597,15 +1610,17 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
         // the queue starts behind the waves' own first reservations (ItemQueue); the walks of trees and sphere sets get one band of
         // items and one queue word per group of blocks that share an XCD
         hipError_t e = hipSuccess;
-        const bool banded = v != PLAIN && RB_XCD_BANDS && li.grid >= kQueueGroups && items >= 64ull * batch * kQueueGroups;
+        // (stripes of about four tile rows, whole multiples of the batch; at least four stripes per band, or one word as before)
+        const uint64_t row_items = (uint64_t)((p.u.width + 7u) / 8u) * 64u * p.n_passes * p.samples_per_pass;
+        const uint64_t stripe = std::max<uint64_t>(((4u * row_items + batch - 1u) / batch) * batch, 8u * batch);
+        const bool banded = v != PLAIN && RB_XCD_BANDS && li.grid >= kQueueGroups && items >= 4u * kQueueGroups * stripe && stripe < (1ull << 30);
         if (banded) {
             q.queue_groups = kQueueGroups;
-            const uint64_t per = (items + kQueueGroups - 1u) / kQueueGroups;
-            q.queue_region = (uint32_t)(((per + batch - 1u) / batch) * batch);
+            q.queue_region = (uint32_t)stripe;
             QueueInit qi;
             for (uint32_t g = 0; g < kQueueGroups; g++) {
                 const uint64_t blocks_g = (li.grid + kQueueGroups - 1u - g) / kQueueGroups;
-                qi.start[g] = (uint32_t)std::min<uint64_t>((uint64_t)g * q.queue_region + blocks_g * (li.block / 64u) * batch, 0xFFFF0000ull);
+                qi.start[g] = (uint32_t)std::min<uint64_t>(blocks_g * (li.block / 64u) * batch, 0x7FFFFFFFull);   // band-local
             }
             hipLaunchKernelGGL(k_queue_init, dim3(1), dim3(64), 0, stream, p.queue, qi);
             e = hipGetLastError();

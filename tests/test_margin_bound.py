@@ -39,3 +39,25 @@ def test_the_emulated_triangle_test_is_the_oracles():
             n_hit += 1
             assert np.float32(to).view(np.uint32) == t[i].view(np.uint32), i
     assert n_hit > 10
+
+
+def test_a_short_adversarial_search_stays_within_the_bounds():
+    # tools/margin_search.py in miniature: the worst of a random sample, nudged by a few ulps per generation towards larger
+    # error / margin; profiles/r03_margin_search.txt has the long run.  The search must climb (it is a search) and stay below 1.
+    ms_spec = importlib.util.spec_from_file_location("margin_search", os.path.join(ROOT, "tools", "margin_search.py"))
+    ms = importlib.util.module_from_spec(ms_spec)
+    ms_spec.loader.exec_module(ms)
+    rng = np.random.default_rng(5)
+    o, d, v0, e1, e2, v1, v2 = mc.batch(rng, 300_000, "floor")
+    S = np.stack(list(o) + list(d) + list(v0) + list(v1) + list(v2)).astype(np.float32)
+    for which in range(3):
+        r = ms.evaluate(S, which)
+        top = np.argsort(r)[-300:]
+        P, best = S[:, top].copy(), r[top].copy()
+        start = best.max()
+        for g in range(6):
+            kids = ms.nudge(rng, P, big=False)
+            rk = ms.evaluate(kids, which)
+            better = rk > best
+            P[:, better], best[better] = kids[:, better], rk[better]
+        assert start > 0.0 and best.max() >= start and best.max() <= 1.0, (which, start, best.max())

@@ -8,7 +8,7 @@ the contract's single IEEE operations) and keep a child if its ratio error / mar
 (the kernels' normalised directions), children whose hit is no longer accepted drop out.  A ratio above 1 would be a
 counterexample.  CPU only.
 
-    python tools/margin_search.py [generations, default 300] [population, default 4000] > profiles/<tag>_margin_search.txt
+    python tools/margin_search.py [generations, default 300] [population, default 4000] [seed, default 777] > profiles/<tag>_margin_search.txt
 """
 import os
 import sys
@@ -61,11 +61,12 @@ def nudge(rng, P, big):
 def main():
     gens = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     pop = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
-    rng = np.random.default_rng(777)
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 777
+    rng = np.random.default_rng(seed)
     names = ("reported point / Sp (27 u F + 24 u)   [section 4.1, k_trace_fast]",
              "exact plane point / S (12 u F' + 24 u) [section 4.2, across the ray]",
              "|t^ - t*| / S (11 u F' + 16 u)         [section 4.2, along the ray]")
-    print(f"# margin_search: {gens} generations, {pop} survivors x 8 children per criterion; seeds = the worst of 6 M random rays; seed 777")
+    print(f"# margin_search: {gens} generations, {pop} survivors x 8 children per criterion; seeds = the worst of 6 M random rays; seed {seed}")
     t0 = time.time()
     # one random sample serves as the seed population of all three searches
     cols = []

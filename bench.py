@@ -95,7 +95,7 @@ def make_scene(name, spp):
         s = scenes.spheres_scene()
         desc = "C4 1M random spheres over a checkerboard ground, 4096x4096, 64 spp, 5 bounces"
     elif name == "lamp":
-        from tests import _refscenes   # data of the reference's own largest fixture scene (tests/golden/ref_fixtures)
+        from renderbaby_amd import refscenes as _refscenes   # data of the reference's own largest fixture scene (tests/golden/ref_fixtures)
         s = _refscenes.ref_lamp()
         desc = ("reference fixture final_cornell_with_lamp_and_spheres.rscn: 68768 tris, 4 spheres, ground, "
                 "2056x2056, 512 spp, 5 bounces")

@@ -231,6 +231,9 @@ enum {
 enum {
     RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
+    RB_FLAG_SPHERE_TREE_HOST = 2048u,   /* more than 64 spheres: build the library's sphere tree on the host (median splits) ... */
+    RB_FLAG_SPHERE_TREE_DEVICE = 4096u, /* ... or on the device (Morton order + LBVH) whatever the count; by default the device
+                                           builds it from 1024 spheres up.  The frame does not depend on the builder. */
     RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first) plus
                               a second pass over the caller's tree for hits reported from near-zero determinants, and accept
                               a hit only if the reference's traversal would have tested it: argued and fuzzed to deliver the
@@ -303,6 +306,11 @@ rb_engine* rb_create_multi(const rb_config* cfg, const rb_options* opt, const in
  * and all call rb_comm_init_rank.  From then on rb_render / rb_iter_next gather the stripes to rank 0, which
  * receives the whole frame; on the other ranks rgba_out may be NULL and nothing is written. */
 #define RB_COMM_ID_BYTES 128
+/* Can this process load RCCL at all (RB_OK) -- so that every rank can say so BEFORE the collective rb_comm_init_rank, and
+ * one that cannot does not leave the others waiting inside it.  Loads the library and resolves its symbols, nothing else:
+ * no id is made (ncclGetUniqueId opens a listening socket and starts a thread that waits for the ranks to check in). */
+int rb_comm_available(void);
+/* On rank 0 only. */
 int rb_comm_unique_id(uint8_t id_out[RB_COMM_ID_BYTES]);
 int rb_comm_init_rank(rb_engine* e, const uint8_t id[RB_COMM_ID_BYTES], uint32_t rank, uint32_t nranks);
 
@@ -416,9 +424,6 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
                  rb_bvh_node* nodes_out, size_t nodes_capacity, size_t* n_nodes,
                  uint32_t* indices_out);
 
-/* Test hook: evaluates the device's f32 /, sqrt, normalize, u32->f32, min/max and
- * dot on n input pairs (out8n: 8*n floats) so tests can check them against
- * IEEE-754 results computed on the host. */
 /* Test aid (host only, no device): builds the chunked walk's tree for this mesh and this caller tree and checks the
  * structural invariants the kernel relies on (every valid slot in exactly one chunk, ranks consistent, references in range,
  * depth within the stack, per child slot an unbounded margin or a box and a bound that cover the triangles below).
@@ -430,7 +435,14 @@ int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh
  * every lane its own 128-byte line of a table of `table_bytes` (0 = 2 MiB, L2-resident) -- in lane accesses per second:
  * the ceiling of the L1 / texture-address path that a lane-per-ray tree walk runs into. */
 int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_per_s);
+/* Test hook: evaluates the device's f32 /, sqrt, normalize, u32->f32, min/max and
+ * dot on n input pairs (out8n: 8*n floats) so tests can check them against
+ * IEEE-754 results computed on the host. */
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
+/* Measurement aid: pass-occupancy counters of k_trace_sph in a library built with -DRB_SPH_PROFILE (tools/sph_profile.py:
+ * outer iterations, begin / node / leaf / finish passes and the lanes, pairs, rounds and survivors in them), summed over
+ * every launch since the last reset.  The product build counts nothing and returns RB_ERR_DEVICE. */
+int rb_debug_walk_profile(uint64_t out16[16], int reset);
 /* Test hook: checks the kernels' fast exact reciprocal against the compiler's correctly rounded
  * 1/b for all 2^23 significands (both signs) at one biased exponent; out16[0] = mismatch count. */
 int rb_debug_rcp_exhaustive(uint32_t biased_exponent, uint32_t* out16);
@@ -449,6 +461,11 @@ const char* rb_last_kernel_name(const rb_engine* e);
  * first rb_dispatch / rb_render that follows an update.  `build_ms`, if not NULL, receives the wall
  * time of that build including its uploads. */
 const char* rb_fast_bvh_builder(const rb_engine* e, float* build_ms);
+
+/* Which builder produced the library's sphere tree (scenes with more than 64 spheres): "device-lbvh", "host-median", or
+ * "" when the engine scans (<= 64 spheres, RB_FLAG_NO_SPHERE_BVH).  Valid after the rb_update that brought the spheres.
+ * `build_ms`, if not NULL, receives the wall time of that build including its uploads. */
+const char* rb_sphere_tree_builder(const rb_engine* e, float* build_ms);
 
 /* Library / device identification for logs. */
 const char* rb_version(void);

@@ -205,14 +205,15 @@ float rbo_intersect_ground(const float o[3], const float d[3], float gh) {
 /* ------------------------------------------------------------ HitRecord -- */
 /* shader.wgsl:53-76: only diffuse, specular, shininess, emissive and
  * texture_index of Material are ever read by the shader; ambient is written
- * but never read, so it is not carried. */
+ * (:365, :560) but never read (:612 is a comment) -- carried all the same, so
+ * that every assignment of the shader has its line here. */
 typedef struct {
     int hit;
     float t;
     v3 pos, normal;
     float uv[2];
     int use_texture;
-    v3 diffuse, specular, emissive;
+    v3 ambient, diffuse, specular, emissive;
     float shininess;
     int32_t texture_index;
 } hitrec;
@@ -221,11 +222,11 @@ static inline void hit_reset(hitrec* h) { /* shader.wgsl:283-297, 535-549 */
     h->hit = 0; h->t = 1e20f;
     h->pos = V(0, 0, 0); h->normal = V(0, 0, 0);
     h->uv[0] = h->uv[1] = 0.0f; h->use_texture = 0;
-    h->diffuse = V(0, 0, 0); h->specular = V(0, 0, 0); h->emissive = V(0, 0, 0);
+    h->ambient = V(0, 0, 0); h->diffuse = V(0, 0, 0); h->specular = V(0, 0, 0); h->emissive = V(0, 0, 0);
     h->shininess = 0.0f; h->texture_index = -1;
 }
 static inline void hit_set_material(hitrec* h, const rb_material* m) {
-    h->diffuse = Vp(m->diffuse); h->specular = Vp(m->specular); h->emissive = Vp(m->emissive);
+    h->ambient = Vp(m->ambient); h->diffuse = Vp(m->diffuse); h->specular = Vp(m->specular); h->emissive = Vp(m->emissive);
     h->shininess = m->shininess; h->texture_index = m->texture_index;
 }
 
@@ -286,6 +287,7 @@ static void intersect_bvh(const ctx_t* c, v3 o, v3 d, hitrec* hit, rbo_stats* st
                         float rgb[3];
                         rbo_hash_to_color(bvh_tri_idx + 1u, rgb);
                         hit->diffuse = Vp(rgb);
+                        hit->ambient = V(0, 0, 0);      /* :365 */
                         hit->specular = V(0, 0, 0);
                         hit->use_texture = 0;
                     } else {
@@ -363,6 +365,7 @@ static v3 trace_ray(const ctx_t* c, v3 origin, v3 direction, uint32_t seed, rbo_
                 closest.pos = add(origin, scale(t, direction));
                 closest.normal = V(0.0f, 1.0f, 0.0f);
                 closest.diffuse = V(0.5f, 0.5f, 0.5f);
+                closest.ambient = V(0, 0, 0);       /* :560 */
                 closest.specular = V(0, 0, 0);
                 closest.uv[0] = closest.pos.x;
                 closest.uv[1] = closest.pos.z;

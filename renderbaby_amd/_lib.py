@@ -41,6 +41,7 @@ def load():
         "rb_create_ex": (vp, [P(abi.Config), P(abi.Options)]),
         "rb_create_multi": (vp, [P(abi.Config), P(abi.Options), P(C.c_int32), u32]),
         "rb_comm_unique_id": (i32, [vp]),
+        "rb_comm_available": (i32, []),
         "rb_comm_init_rank": (i32, [vp, vp, u32, u32]),
         "rb_comm_info": (i32, [vp, P(u32), P(u32), P(C.c_float)]),
         "rb_destroy": (None, [vp]),
@@ -73,10 +74,12 @@ def load():
         "rb_debug_chunk_tree": (i32, [vp, sz, vp, sz, vp, sz, vp]),
         "rb_measure_l1_gather": (i32, [i32, C.c_uint64, P(C.c_double)]),
         "rb_debug_math": (i32, [vp, vp, vp, u32]),
+        "rb_debug_walk_profile": (i32, [vp, i32]),
         "rb_debug_rcp_exhaustive": (i32, [u32, vp]),
         "rb_debug_div_exhaustive": (i32, [u32, u32, u32, u32, u32, u32, vp]),
         "rb_last_kernel_name": (C.c_char_p, [vp]),
         "rb_fast_bvh_builder": (C.c_char_p, [vp, vp]),
+        "rb_sphere_tree_builder": (C.c_char_p, [vp, vp]),
         "rb_version": (C.c_char_p, []),
         "rb_device_name": (i32, [i32, C.c_char_p, sz]),
     }
@@ -102,8 +105,8 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
-EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_unique_id", "rb_comm_init_rank", "rb_comm_info", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
+EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_available", "rb_comm_unique_id", "rb_comm_init_rank", "rb_comm_info", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_iter_set_passes_per_frame", "rb_last_error",
            "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
            "rb_device_rgba", "rb_host_alloc", "rb_host_free", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",
-           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_version", "rb_device_name"]
+           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_walk_profile", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_sphere_tree_builder", "rb_version", "rb_device_name"]

@@ -71,6 +71,8 @@ FLAG_GATHER_PEER_COPY = 128
 FLAG_NO_RUN_AHEAD = 256
 FLAG_SKIP_NEAR_DEGENERATE = 512
 FLAG_CHUNK_WALK = 1024
+FLAG_SPHERE_TREE_HOST = 2048
+FLAG_SPHERE_TREE_DEVICE = 4096
 COMM_ID_BYTES = 128
 
 

@@ -420,7 +420,229 @@ __global__ void k_ploc_finish(PlocClusters c, const uint32_t* __restrict__ bound
 
 inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
 
+// ---- The sphere tree (BASELINE C4: 10^6 spheres; rb_device_shade.hpp SphereWalk, rb_kernels.hip k_trace_sph) built on
+// the device: Morton order of the centres, leaves = kSphLeaf consecutive spheres of that order (one 16-byte {centre,
+// radius} record each, so the lanes that test a leaf read consecutive bytes), and the LBVH of this file over the leaves'
+// first keys.  The tree only steers the walk -- every candidate goes through the reference's intersect_sphere and ties
+// resolve by the original index -- so the frame is the same bits as with the host's median-split tree (rb_bvh.cpp), which
+// stays as the fallback (a tree deeper than the LDS stack) and as the checker (tests/test_gpu_sphere_tree.py).
+__global__ void __launch_bounds__(256) k_sph_bounds(const rb_sphere* __restrict__ spheres, uint32_t n, uint32_t* bounds) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const float inf = __builtin_inff();
+    float cn[3] = {inf, inf, inf}, cx[3] = {-inf, -inf, -inf};
+    if (i < n) {
+        const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)i * 6u];
+        cn[0] = cx[0] = cr.x; cn[1] = cx[1] = cr.y; cn[2] = cx[2] = cr.z;
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            cn[a] = fminf(cn[a], __shfl_xor(cn[a], off, 64));
+            cx[a] = fmaxf(cx[a], __shfl_xor(cx[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bounds[6 + a], f2ord(cn[a]));
+            atomicMax(&bounds[9 + a], f2ord(cx[a]));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sph_keys(const rb_sphere* __restrict__ spheres, uint32_t n, const uint32_t* __restrict__ bounds,
+                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ items) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)i * 6u];
+    const float c[3] = {cr.x, cr.y, cr.z};
+    // one scale for the three axes (the largest extent): the cells are cubes, so a flat scene (C4: 200 x 20 x 200) is cut
+    // along its long axes first instead of into slabs a tenth as thick as they are wide
+    float ext = 0.0f;
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, ord2f(bounds[9 + k]) - ord2f(bounds[6 + k]));
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ord2f(bounds[6 + k]);
+        float x = (ext > 0.0f) ? (c[k] - lo) / ext * 2097152.0f : 0.0f;
+        x = fminf(fmaxf(x, 0.0f), 2097151.0f);  // NaN -> 0
+        q[k] = static_cast<uint32_t>(x);
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    items[i] = i;
+}
+
+// one thread per sphere of the sorted order: its leaf record and original index; one thread per leaf: the leaf's box
+// (c -+ r in f32: what the walk's margin allows for, rb_device_shade.hpp kSphAbs) and first key
+__global__ void __launch_bounds__(256) k_sph_leaves(const rb_sphere* __restrict__ spheres, const uint32_t* __restrict__ items,
+                                                     const unsigned long long* __restrict__ keys, uint32_t n, uint32_t n_leaf,
+                                                     float4* __restrict__ leaf_out, uint32_t* __restrict__ id_out,
+                                                     float4* __restrict__ lmin, float4* __restrict__ lmax,
+                                                     unsigned long long* __restrict__ lkeys, uint32_t* __restrict__ ident) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        const uint32_t id = items[i];
+        leaf_out[i] = reinterpret_cast<const float4*>(spheres)[(size_t)id * 6u];
+        id_out[i] = id;
+    }
+    if (i < n_leaf) {
+        const uint32_t first = i * kSphLeaf, end = (first + kSphLeaf < n) ? first + kSphLeaf : n;
+        const float inf = __builtin_inff();
+        float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+        for (uint32_t j = first; j < end; ++j) {
+            const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)items[j] * 6u];
+            const float c[3] = {cr.x, cr.y, cr.z};
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], c[a] - cr.w);
+                mx[a] = fmaxf(mx[a], c[a] + cr.w);
+            }
+        }
+        lmin[i] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        lmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        lkeys[i] = keys[first];
+        ident[i] = i;
+    }
+}
+
+// bottom-up boxes and heights over the leaves' LBVH (as k_lbvh_refit, every internal node a real node)
+__global__ void __launch_bounds__(256) k_sph_refit(uint32_t n_leaf, const float4* __restrict__ lmin, const float4* __restrict__ lmax,
+                                                    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                    const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent,
+                                                    uint32_t* flags, float4* nmin, float4* nmax) {
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= n_leaf) return;
+    uint32_t cur = leaf_parent[pos];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&flags[cur], 1u) == 0u) return;  // the sibling subtree is not finished yet
+        __threadfence();
+        float4 lo[2], hi[2];
+        uint32_t hgt[2];
+        const uint32_t ch[2] = {left[cur], right[cur]};
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] & kLeafTag) {
+                lo[k] = lmin[ch[k] & ~kLeafTag];
+                hi[k] = lmax[ch[k] & ~kLeafTag];
+                hgt[k] = 0u;
+            } else {
+                lo[k] = nmin[ch[k]];  // written by another CU: the fence above has invalidated L1
+                hi[k] = nmax[ch[k]];
+                hgt[k] = __float_as_uint(hi[k].w);
+            }
+        }
+        const uint32_t h = (hgt[0] > hgt[1] ? hgt[0] : hgt[1]) + 1u;
+        nmin[cur] = make_float4(fminf(lo[0].x, lo[1].x), fminf(lo[0].y, lo[1].y), fminf(lo[0].z, lo[1].z), 0.0f);
+        nmax[cur] = make_float4(fmaxf(hi[0].x, hi[1].x), fmaxf(hi[0].y, hi[1].y), fmaxf(hi[0].z, hi[1].z), __uint_as_float(h));
+        if (cur == 0u) return;
+        cur = parent[cur];
+    }
+}
+
+__device__ __forceinline__ uint32_t sph_leaf_ref(uint32_t leaf, uint32_t n) {
+    const uint32_t first = leaf * kSphLeaf, cnt = (n - first < kSphLeaf) ? n - first : kSphLeaf;
+    return kLeafTag | ((cnt - 1u) << 27) | first;
+}
+
+__global__ void __launch_bounds__(256) k_sph_emit(uint32_t n, uint32_t n_leaf, const float4* __restrict__ lmin,
+                                                   const float4* __restrict__ lmax, const uint32_t* __restrict__ left,
+                                                   const uint32_t* __restrict__ right, const float4* __restrict__ nmin,
+                                                   const float4* __restrict__ nmax, SphereNode* __restrict__ nodes,
+                                                   DeviceSphereTreeInfo* info) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 1u < n_leaf) {
+        float4 o[4];
+        uint32_t ref[2];
+        const uint32_t ch[2] = {left[i], right[i]};
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] & kLeafTag) {
+                const uint32_t leaf = ch[k] & ~kLeafTag;
+                o[2 * k] = lmin[leaf];
+                o[2 * k + 1] = lmax[leaf];
+                ref[k] = sph_leaf_ref(leaf, n);
+            } else {
+                o[2 * k] = nmin[ch[k]];
+                o[2 * k + 1] = nmax[ch[k]];
+                ref[k] = ch[k];
+            }
+        }
+        SphereNode nd;
+        nd.lmin[0] = o[0].x; nd.lmin[1] = o[0].y; nd.lmin[2] = o[0].z; nd.left = ref[0];
+        nd.lmax[0] = o[1].x; nd.lmax[1] = o[1].y; nd.lmax[2] = o[1].z; nd.right = ref[1];
+        nd.rmin[0] = o[2].x; nd.rmin[1] = o[2].y; nd.rmin[2] = o[2].z; nd._pad0 = 0u;
+        nd.rmax[0] = o[3].x; nd.rmax[1] = o[3].y; nd.rmax[2] = o[3].z; nd._pad1 = 0u;
+        nodes[i] = nd;
+    }
+    if (i == 0u) {
+        info->root = n_leaf > 1u ? 0u : sph_leaf_ref(0u, n);
+        info->depth = n_leaf > 1u ? __float_as_uint(nmax[0].w) + 1u : 1u;   // entries the walk's stack can hold at once: <= internal levels
+    }
+}
+
 }  // namespace
+
+int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode* nodes_out, float* leaf_out, uint32_t* id_out,
+                            DeviceSphereTreeInfo* info_out, void* stream_) {
+    if (n == 0u || n >= (1u << 27)) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using key_t = unsigned long long;
+    const uint32_t n_leaf = (n + kSphLeaf - 1u) / kSphLeaf;
+    size_t sort_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<key_t*>(nullptr), static_cast<key_t*>(nullptr),
+                                             static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n, 0, 63, stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    const size_t o_keys_in = carve(sizeof(key_t) * n), o_keys = carve(sizeof(key_t) * n);
+    const size_t o_items_in = carve(4u * n), o_items = carve(4u * n);
+    const size_t o_lmin = carve(16u * n_leaf), o_lmax = carve(16u * n_leaf), o_nmin = carve(16u * n_leaf), o_nmax = carve(16u * n_leaf);
+    const size_t o_lkeys = carve(sizeof(key_t) * n_leaf), o_ident = carve(4u * n_leaf);
+    const size_t o_left = carve(4u * n_leaf), o_right = carve(4u * n_leaf), o_first = carve(4u * n_leaf), o_size = carve(4u * n_leaf);
+    const size_t o_parent = carve(4u * n_leaf), o_leafpar = carve(4u * n_leaf), o_flags = carve(4u * n_leaf);
+    const size_t o_bounds = carve(64), o_info = carve(sizeof(DeviceSphereTreeInfo)), o_sort = carve(sort_bytes);
+    char* base = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&base), off);
+    if (e != hipSuccess) return static_cast<int>(e);
+    auto at = [&](size_t o) { return base + o; };
+    auto done = [&](hipError_t err) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(base);
+        return static_cast<int>(err);
+    };
+    key_t* keys_in = reinterpret_cast<key_t*>(at(o_keys_in));
+    key_t* keys = reinterpret_cast<key_t*>(at(o_keys));
+    uint32_t* items_in = reinterpret_cast<uint32_t*>(at(o_items_in));
+    uint32_t* items = reinterpret_cast<uint32_t*>(at(o_items));
+    float4 *lmin = reinterpret_cast<float4*>(at(o_lmin)), *lmax = reinterpret_cast<float4*>(at(o_lmax));
+    float4 *nmin = reinterpret_cast<float4*>(at(o_nmin)), *nmax = reinterpret_cast<float4*>(at(o_nmax));
+    key_t* lkeys = reinterpret_cast<key_t*>(at(o_lkeys));
+    uint32_t* ident = reinterpret_cast<uint32_t*>(at(o_ident));
+    uint32_t *left = reinterpret_cast<uint32_t*>(at(o_left)), *right = reinterpret_cast<uint32_t*>(at(o_right));
+    uint32_t *rfirst = reinterpret_cast<uint32_t*>(at(o_first)), *rsize = reinterpret_cast<uint32_t*>(at(o_size));
+    uint32_t *parent = reinterpret_cast<uint32_t*>(at(o_parent)), *leafpar = reinterpret_cast<uint32_t*>(at(o_leafpar));
+    uint32_t* flags = reinterpret_cast<uint32_t*>(at(o_flags));
+    uint32_t* bounds = reinterpret_cast<uint32_t*>(at(o_bounds));
+    DeviceSphereTreeInfo* d_info = reinterpret_cast<DeviceSphereTreeInfo*>(at(o_info));
+    const uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u,
+                               0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const dim3 grid((n + 255u) / 256u), lgrid((n_leaf + 255u) / 256u), block(256);
+    e = hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return done(e);
+    e = hipMemsetAsync(flags, 0, 4u * n_leaf, stream);
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(k_sph_bounds, grid, block, 0, stream, spheres, n, bounds);
+    hipLaunchKernelGGL(k_sph_keys, grid, block, 0, stream, spheres, n, bounds, keys_in, items_in);
+    e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_in, keys, items_in, items, n, 0, 63, stream);
+    if (e != hipSuccess) return done(e);
+    hipLaunchKernelGGL(k_sph_leaves, grid, block, 0, stream, spheres, items, keys, n, n_leaf, reinterpret_cast<float4*>(leaf_out),
+                       id_out, lmin, lmax, lkeys, ident);
+    if (n_leaf > 1u) {
+        hipLaunchKernelGGL(k_lbvh_hierarchy, lgrid, block, 0, stream, lkeys, n_leaf, left, right, rfirst, rsize, parent, leafpar);
+        hipLaunchKernelGGL(k_sph_refit, lgrid, block, 0, stream, n_leaf, lmin, lmax, left, right, parent, leafpar, flags, nmin, nmax);
+    }
+    hipLaunchKernelGGL(k_sph_emit, lgrid, block, 0, stream, n, n_leaf, lmin, lmax, left, right, nmin, nmax, nodes_out, d_info);
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(e);
+    e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipMemcpy(info_out, d_info, sizeof(DeviceSphereTreeInfo), hipMemcpyDeviceToHost);
+    return done(e);
+}
 
 // All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).
 int device_fast_bvh_build(const rb_gpu_triangle* tris, const uint32_t* indices, const uint32_t* slots, uint32_t n,

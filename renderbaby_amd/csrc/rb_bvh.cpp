@@ -185,10 +185,10 @@ struct SBuilder {
             }
         }
     }
-    // returns a child reference: leaf = 0x80000000 | (count-1) << 28 | first ; node = index
+    // returns a child reference: leaf = 0x80000000 | (count-1) << 27 | first ; node = index
     uint32_t build(size_t first, size_t count, uint32_t depth) {
         max_depth = std::max(max_depth, depth);
-        if (count <= 4) return 0x80000000u | (static_cast<uint32_t>(count - 1) << 28) | static_cast<uint32_t>(first);
+        if (count <= kSphLeaf) return 0x80000000u | (static_cast<uint32_t>(count - 1) << 27) | static_cast<uint32_t>(first);
         float cmn[3], cmx[3];
         for (int a = 0; a < 3; ++a) {
             cmn[a] = std::numeric_limits<float>::infinity();

@@ -15,17 +15,10 @@ namespace {
 // costs a v_readlane, a vector-unit slot.  Starting a phase of the loop from a pointer the compiler cannot see
 // through makes that phase load what it needs with scalar loads (the scalar cache holds them) and ends the live
 // ranges at the phase's end.  k_trace on C2: 411 -> 78 v_readlane in the loop body, + 5.6 % (profiles/r02_fresh_params.txt).
-#ifndef RB_FRESH_PARAMS
-#define RB_FRESH_PARAMS 1
-#endif
-DEV const KParams& fresh_params(const KParams& p) {
-#if RB_FRESH_PARAMS
+DEV const KParams& fresh_params(const KParams&) {
     const RB_CONST char* k = (const RB_CONST char*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     return *(const KParams*)k;
-#else
-    return p;
-#endif
 }
 
 struct Mat {
@@ -67,26 +60,56 @@ DEV bool near_zero(f3 v) {                                                // :46
     return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
 }
 
-// Sphere acceleration structure (rb_bvh.cpp, sphere_bvh_build): closest sphere with the
-// semantics of the reference's linear scan (shader.wgsl:574-586).
+// Sphere acceleration structure (rb_bvh.cpp sphere_bvh_build on the host, rb_build.hip device_sphere_bvh_build on the
+// device): closest sphere with the semantics of the reference's linear scan (shader.wgsl:574-586).
 //  * every candidate is evaluated with the reference's exact intersect_sphere;
 //  * the scan accepts `t > 0.001 && t < closest.t` in index order, i.e. the winner is the
 //    smallest t below the incoming closest_t, ties going to the lowest index: here
 //    `t < best || (t == best && id < best_id)`;
-//  * a subtree is skipped only if the ray misses its box inflated by a margin, or enters it beyond
-//    best_t.  The margin covers the rounding error of the reference's own arithmetic: its discriminant
-//    hb^2 - a*(|oc|^2 - r^2) carries an absolute error <= 16 u a |oc|^2 (u = 2^-24), so a sphere
-//    can be reported hit by a ray passing up to sqrt(r^2 + 1e-6 |oc|^2) from its centre and the
-//    reported t can be early by about the same amount.  For every sphere below a box, |oc| <= D =
-//    distance from the ray origin to the box's farthest corner; 3e-3 * D (> 2 * sqrt(1e-6) * D)
-//    bounds both.
-#ifndef RB_SPHERE_NODE_MARGIN
-#define RB_SPHERE_NODE_MARGIN 1
-#endif
-// Resumable (like FastWalk): the per-segment kernels run it to completion, k_trace_sph steps it.
+//  * a subtree is skipped only if no sphere below it can be REPORTED hit nearer than the best t so far.  The reference's
+//    discriminant hb^2 - a (|oc|^2 - r^2) carries an absolute error <= E u a D^2 (u = 2^-24; D >= max(|oc|, r); E < 24:
+//    tools/sphere_margin_check.py measures 7.1 at most, first-order bound 20), so
+//      across the ray: a sphere is reported hit only by a ray whose LINE passes within r + sqrt(E u) D of its centre:
+//        the line's point nearest the centre (parameter t_c) lies in the sphere's box grown by mm = kSphK D;
+//      along the ray: the reported t^ = t_c -+ sqrt(disc^) / a is within dt = kSphK D / |d| of a point of the chord
+//        (or of t_c itself when the exact line misses the sphere).
+//    So with [tn, tf] = where the line is inside the child's box grown by mm, every reported t^ of a sphere below lies
+//    in [tn - dt, tf + dt]; it must be positive and, to win, below the best t.  D = distance from the origin to the box's
+//    farthest corner >= max(|oc|, r) for every sphere inside the box.  kSphK = 1.25e-3 = sqrt(26 u): both parts of
+//    r03's single 3e-3 D box inflation, each now where it belongs (a third of the cross-section on far boxes).
+constexpr float kSphK = 1.25e-3f * 1.001f;   // * 1.001: v_sqrt_f32 / v_rsq_f32 are within 1 ulp, the slab arithmetic a few more
+constexpr float kSphAbs = 1e-4f;             // absolute part: the boxes' own rounding (c -+ r in f32), tiny scenes
+struct SphereCull {
+    float mm, dt;
+};
+// one child box: enter?  `tn` = where the line enters the grown box (nearer child first).  NaN anywhere means "enter".
+DEV bool sphere_child(v4f lo, v4f hi, f3 o, f3 inv, float rs, float best, float& tn) {
+    const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
+    float mx, my, mz;
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(a.x), "v"(b.x));
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(my) : "v"(a.y), "v"(b.y));
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mz) : "v"(a.z), "v"(b.z));
+    const float D = __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz)));
+    const float mm = __builtin_fmaf(kSphK, D, kSphAbs), dt = mm * rs;
+    const f3 t0 = a * inv, t1 = b * inv;
+    const float ix = fabsf(inv.x), iy = fabsf(inv.y), iz = fabsf(inv.z);
+    tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, fminf(t0.x, t1.x)), __builtin_fmaf(-mm, iy, fminf(t0.y, t1.y))),
+               __builtin_fmaf(-mm, iz, fminf(t0.z, t1.z)));
+    const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fmaxf(t0.x, t1.x)), __builtin_fmaf(mm, iy, fmaxf(t0.y, t1.y))),
+                           __builtin_fmaf(mm, iz, fmaxf(t0.z, t1.z)));
+    return !(tf < tn) && !(tf < -dt) && !(tn - dt > best);
+}
+
+// Leaf reference: bit 31, (count - 1) << 27, first position in leaf order; at most kSphLeaf spheres, consecutive
+// 16-byte {centre, radius} records (sph_leaf) with their original indices beside them (sph_id).
+DEV uint32_t sph_leaf_first(uint32_t ref) { return ref & 0x07FFFFFFu; }
+DEV uint32_t sph_leaf_count(uint32_t ref) { return ((ref >> 27) & 15u) + 1u; }
+
+// The per-lane form: resumable (like FastWalk); the per-segment kernels and segment_finish run it to completion,
+// k_trace_sph has its own pooled walk (rb_kernels.hip).
 struct SphereWalk {
     f3 o, d, inv;
-    float a, m, best;
+    float a, rs, best;
     uint32_t best_id, cur;
     int sp;
 
@@ -94,11 +117,7 @@ struct SphereWalk {
         o = o_;
         d = d_;
         a = a_;
-        const f3 bmin = ld3(p.sph_bmin), bmax = ld3(p.sph_bmax);
-        const float dx = fmaxf(fabsf(o.x - bmin.x), fabsf(o.x - bmax.x));
-        const float dy = fmaxf(fabsf(o.y - bmin.y), fabsf(o.y - bmax.y));
-        const float dz = fmaxf(fabsf(o.z - bmin.z), fabsf(o.z - bmax.z));
-        m = 3e-3f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-4f;
+        rs = 1.001f * __builtin_amdgcn_rsqf(a_);   // 1 / |d|
         inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
         best = closest_t;
         best_id = 0xFFFFFFFFu;
@@ -112,33 +131,13 @@ struct SphereWalk {
         cur = stack[sp * stride];
         return true;
     }
-    // slab test of a box inflated by its own margin: visit unless missed or entered beyond `best`
-    // (comparisons are written so that a NaN means "visit").  The margin covers the rounding error of
-    // the reference's discriminant, which grows with |origin - centre|^2 of the sphere at hand: for the
-    // spheres below this box that distance is at most the distance to the box's farthest corner, so
-    // nearby subtrees get a margin far below the scene-wide one (RB_SPHERE_NODE_MARGIN=0 restores it).
-    DEV bool entry(v4f lo, v4f hi, float& tn) const {
-        const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
-#if RB_SPHERE_NODE_MARGIN
-        const float fx = fmaxf(fabsf(a.x), fabsf(b.x)), fy = fmaxf(fabsf(a.y), fabsf(b.y)), fz = fmaxf(fabsf(a.z), fabsf(b.z));
-        // v_sqrt_f32 is within 1 ulp; 3.001e-3 keeps the product above 3e-3 * the exact root
-        const float mm = 3.001e-3f * __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) + 1e-4f;
-#else
-        const float mm = m;
-#endif
-        const f3 t0 = mk(a.x - mm, a.y - mm, a.z - mm) * inv;
-        const f3 t1 = mk(b.x + mm, b.y + mm, b.z + mm) * inv;
-        tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
-        const float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
-        return !(tf < fmaxf(tn, 0.0f)) && !(tn > best);
-    }
     // false when the walk is complete
     DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride) {
         const cf4p nodes = (cf4p)p.sph_nodes;
         const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
         const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
         float tl_, tr_;
-        const bool hl = entry(l0, l1, tl_), hr = entry(r0, r1, tr_);
+        const bool hl = sphere_child(l0, l1, o, inv, rs, best, tl_), hr = sphere_child(r0, r1, o, inv, rs, best, tr_);
         if (hl && hr) {
             // nearer child first; the other waits on the stack
             const bool left_first = !(tr_ < tl_);
@@ -160,7 +159,7 @@ struct SphereWalk {
     DEV bool leaf_step(const KParams& p, uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
         const cf4p leafs = (cf4p)p.sph_leaf;
         const RB_CONST uint32_t* ids = cptr(p.sph_id);
-        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 3u) + 1u;
+        const uint32_t first = sph_leaf_first(cur), count = sph_leaf_count(cur);
         for (uint32_t j = first; j < first + count; j++) {
             const v4f cr = leafs[j];
             const uint32_t id = ids[j];

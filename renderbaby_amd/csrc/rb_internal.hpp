@@ -12,6 +12,14 @@
 namespace rb {
 
 constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (LDS)
+// The traversal stacks of a block are ONE region of LDS, s_stack[entry][thread]: 4-byte entries in columns of
+// KParams::stack_depth entries, sized by launch_render.  Every walk a kernel runs -- the caller's tree, the chunked or the
+// library's tree, and the sphere tree inside segment_finish -- uses the calling lane's column, one walk at a time.  An entry
+// wider than kStackEntryBytes, or a walk deeper than stack_depth, runs into the neighbouring lane's column (r03: an
+// experiment with 8-byte entries in k_trace_chunk did, and a lane popped a corrupted reference: a GPU memory fault).  The
+// kernels assert the entry size where they take their column (StackColumn), the runtime the depth where it sets
+// stack_depth (stack_depth_covers).
+constexpr uint32_t kStackEntryBytes = 4;
 constexpr uint32_t kDefaultStripeRows = 16;
 
 // ---- rb_bvh.cpp
@@ -20,10 +28,16 @@ void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_no
 bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_stack, std::string& why,
                   uint32_t* depth_out);
 
-// Sphere acceleration structure (no reference counterpart; see rb_bvh.cpp).  64 B per node.
+// Sphere acceleration structure (no reference counterpart; see rb_bvh.cpp).  64 B per node.  (The library's own triangle
+// tree of DESIGN.md section 4.1 uses the same node with leaves of <= 2: 0x80000000 | (count-1) << 28 | first.)
+#ifndef RB_SPH_LEAF
+#define RB_SPH_LEAF 16
+#endif
+constexpr uint32_t kSphLeaf = RB_SPH_LEAF;   // spheres per leaf = lanes per (ray, leaf) pair of k_trace_sph: 8 or 16
+static_assert(kSphLeaf == 8 || kSphLeaf == 16, "a sphere leaf is tested by 8 or 16 lanes");
 struct alignas(16) SphereNode {
     float lmin[3];
-    uint32_t left;    // child reference: node index, or leaf = 0x80000000 | (count-1) << 28 | first
+    uint32_t left;    // child reference: node index, or sphere leaf = 0x80000000 | (count-1) << 27 | first (count <= kSphLeaf)
     float lmax[3];
     uint32_t right;
     float rmin[3];
@@ -33,9 +47,18 @@ struct alignas(16) SphereNode {
 };
 static_assert(sizeof(SphereNode) == 64, "SphereNode is 64 B");
 constexpr uint32_t kSphereBvhThreshold = 64;  // use the linear two-pass scan up to this many spheres
+constexpr uint32_t kSphereDeviceBuildMin = 1024;  // from here up the sphere tree is built on the device by default
 void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode>& nodes,
                       std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
                       float bmax[3]);
+// The same structure made on the device (rb_build.hip): Morton order of the centres, leaves of kSphLeaf consecutive
+// spheres, an LBVH over the leaves.  `spheres` is the device copy; nodes_out holds ceil(n / kSphLeaf) - 1 nodes,
+// leaf_out n float4 {centre, radius}, id_out n original indices.  Synchronises `stream`.
+struct DeviceSphereTreeInfo {
+    uint32_t root, depth;
+};
+int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode* nodes_out, float* leaf_out, uint32_t* id_out,
+                            DeviceSphereTreeInfo* info_out, void* stream);
 
 // Walk of multi-node meshes when the caller's flags do not say: the chunked walk (ChunkTree below),
 // at every size.  Should its tree not be buildable (a tree deeper than the LDS stack, a leaf root), the library's own
@@ -233,9 +256,7 @@ struct KParams {
     const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
     const float* sph_leaf;         // float4 {centre, radius} in leaf order
     const uint32_t* sph_id;        // original sphere index per leaf-order slot
-    float sph_bmin[3];             // bounds of all spheres (for the per-ray error margin)
     uint32_t sph_root;             // root child reference
-    float sph_bmax[3];
     uint32_t _pad_sph;
     const float* accum_in;         // local_rows_padded * width * 4: the accumulation this launch resumes ...
     float* accum_out;              // ... and the one it writes (the same buffer, or the other frame slot when a pass runs ahead)
@@ -288,6 +309,7 @@ int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint3
                           uint32_t a_count, unsigned long long* mismatch16, void* stream);
 int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch16, void* stream);
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);
+int debug_sph_profile(unsigned long long* out16, int reset);   // pass occupancy of k_trace_sph in a -DRB_SPH_PROFILE build (-1 otherwise)
 double measure_l1_gather(size_t table_bytes, uint32_t rounds);   // divergent 16-byte gathers from an L2-resident table: lane accesses / s
 int device_cu_count(int device);
 uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu);  // upper bound of grid * block of the stream kernels

@@ -20,6 +20,13 @@
 namespace rb {
 namespace {
 
+// This lane's column of the block's traversal stacks (rb_internal.hpp, kStackEntryBytes): entry k at column[k * block].
+template <class Entry>
+DEV Entry* stack_column(Entry* s_stack, uint32_t tid) {
+    static_assert(sizeof(Entry) == kStackEntryBytes, "the traversal stacks are columns of 4-byte entries shared by every walk of a kernel");
+    return &s_stack[tid];
+}
+
 // ======================================================= kernel: PIXEL ====
 // One thread per pixel, 8x8 pixels per wavefront, nested sample / bounce loops:
 // the shape of the reference's dispatch (one invocation = one pixel,
@@ -204,9 +211,6 @@ DEV void store_color(float4* __restrict__ colors, uint32_t item, f3 c) {
 // slice is marked (kDirect in its item word) and stores on its own when it finishes, as every lane used to.
 // Nothing is ever parked in an occupied entry: the slice was emptied before its row's first item went out, and
 // the stragglers of the previous row were marked in the same step.
-#ifndef RB_COLOR_COMBINE
-#define RB_COLOR_COMBINE 1
-#endif
 constexpr uint32_t kRingRows = 4u, kDirect = 0x80000000u;
 // LDS-qualified pointers: with generic ones the compiler folds "park or store directly" into one FLAT store through a
 // selected address, which is slower than either and loses the streaming hint
@@ -381,21 +385,17 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t width = p.u.width;
-    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_x = (p.u.width + 7u) / 8u;
     const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
     const uint32_t S = p.n_passes * p.samples_per_pass;
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;  // host keeps this < 2^31
-    [[maybe_unused]] const uint32_t sample_base = p.first_pass * p.samples_per_pass;
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
     Tally<STATS> tl;
-#if RB_COLOR_COMBINE
     __shared__ __attribute__((aligned(16))) v4f s_ring[(kTraceBlock / 64u) * kRingRows * 64u];
     ColorRing cring(s_ring, tid >> 6, lane);
     // rows follow each other through the ring's slices only if every reservation starts on a multiple of
     // kRingRows rows; the launcher arranges that for frames large enough, the others store directly
     const uint32_t direct_mask = (p.queue_batch % (kRingRows * 64u)) ? kDirect : 0u;
-#endif
 
     bool active = false, exhausted = false;
     uint32_t item = 0;
@@ -428,39 +428,28 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
                 loc_next = b;
                 loc_end = (total_items - b < batch) ? total_items : b + batch;
             }
-#if RB_FRESH_PARAMS
             // the launch constants this round needs, fetched again from the kernel arguments (scalar loads): held in
             // scalar registers across the segment code they would be spilled and come back through v_readlane, one
             // vector-unit slot each
             const KParams& rp = fresh_params(p);
             const uint32_t rS = rp.n_passes * rp.samples_per_pass, r_tiles_x = (rp.u.width + 7u) / 8u;
             const uint32_t r_sample_base = rp.first_pass * rp.samples_per_pass, r_width = rp.u.width;
-#else
-            const KParams& rp = p;
-            const uint32_t rS = S, r_tiles_x = tiles_x, r_sample_base = sample_base, r_width = width;
-#endif
             const ItemRows rows = item_rows(rp, loc_next, rS, r_tiles_x, r_sample_base);
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = !active && rank < avail;
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const uint32_t taken = n_idle < avail ? n_idle : avail;
-#if RB_COLOR_COMBINE
             if (direct_mask == 0u) {
                 if (rows.in0 == 0u) cring.open_row(colors, lane, loc_next >> 6, active, item);
                 else if (rows.in0 + taken > 64u) cring.open_row(colors, lane, (loc_next >> 6) + 1u, active, item);
             }
-#endif
             if (take) {
                 const uint32_t it = loc_next + rank;
                 uint32_t x = 0, y = 0, sample_hash = 0;
                 if (item_pixel(rp, rows, rank, x, y, sample_hash)) {
                     start_path_hashed(rp, x, y, y * r_width + x, sample_hash, pt);
-#if RB_COLOR_COMBINE
                     item = it | direct_mask;
-#else
-                    item = it;
-#endif
                     if (p.u.max_depth > 0u) {
                         active = true;
                     } else {
@@ -480,19 +469,13 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(const KParams p) {
         if (active) {
             const bool alive = segment<STATS, MULTI>(p, pt, &s_stack[tid], kTraceBlock, tl);
             if (!alive) {
-#if RB_COLOR_COMBINE
                 cring.finish(colors, item, pt.color);
-#else
-                store_color(colors, item, pt.color);
-#endif
                 tl.paths++;
                 active = false;
             }
         }
     }
-#if RB_COLOR_COMBINE
     for (uint32_t k = 0; k < kRingRows; k++) cring.drain(colors, lane, k);
-#endif
     flush_tally<STATS>(tl, p.counters);
 }
 
@@ -527,7 +510,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
     const cf4p nodes = (cf4p)p.nodes;
     const cf4p ptris = (cf4p)p.ptris;
-    uint32_t* const stack = &s_stack[tid];
+    uint32_t* const stack = stack_column(s_stack, tid);
     Tally<STATS> tl;
 
     v4f* const lds_nodes = reinterpret_cast<v4f*>(s_stack + p.stack_depth * BLOCK);
@@ -630,15 +613,6 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
         {
             const uint32_t end = (first + count < p.index_len) ? first + count : p.index_len;  // guard :331
             uint32_t slot = first;
-#if RB_TRI_PAIRS
-            for (; slot + 2u <= end; slot += 2u) {
-                const v4f a0 = tri_q(slot, 0u), b0 = tri_q(slot, 1u), c0 = tri_q(slot, 2u);
-                const v4f a1 = tri_q(slot + 1u, 0u), b1 = tri_q(slot + 1u, 1u), c1 = tri_q(slot + 1u, 2u);
-                const bool ok0 = __float_as_uint(c0.w) != 0u, ok1 = __float_as_uint(c1.w) != 0u;
-                if constexpr (STATS) tl.tris += (ok0 ? 1u : 0u) + (ok1 ? 1u : 0u);
-                test_pair(a0, b0, c0, ok0, a1, b1, c1, ok1, slot, pt.o, pt.d, th, tl);
-            }
-#endif
             for (; slot < end; slot++) {
                 const v4f a = tri_q(slot, 0u), b = tri_q(slot, 1u), c = tri_q(slot, 2u);
                 if (__float_as_uint(c.w) == 0u) continue;  // guard :336
@@ -692,24 +666,12 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #ifndef RB_CHUNK_LEAF_LANES
 #define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)
 #endif
-#ifndef RB_CHUNK_SP
-#define RB_CHUNK_SP 0            // Sp of a child box: 0 = Euclidean distance to its farthest corner, 1 = by the largest component (3 % slower: wider margins)
-#endif
-#ifndef RB_CHUNK_CONT
-#define RB_CHUNK_CONT 1          // 1 = the bound of L^2 / |a^| from the ray's own cone bound of |cos|, 0 = the fixed c0 of section 4.1 (1-2 % slower)
-#endif
-#ifndef RB_CHUNK_DEFER
-#define RB_CHUNK_DEFER 1         // a lane that reaches a chunk puts it aside and walks on to its next one before it waits
-#endif
-#ifndef RB_CHUNK_PIPE
-#define RB_CHUNK_PIPE 1          // request the next round's records before testing this round's
-#endif
 #ifndef RB_CHUNK_FINISH_LANES
 #define RB_CHUNK_FINISH_LANES 32 // shade once this many lanes have finished their walk (or nobody walks)
 #endif
-#ifndef RB_CHUNK_SPLIT
-#define RB_CHUNK_SPLIT 1         // 1 = the margin in its two parts: across the ray (inflates the box) and along it (widens the interval
-#endif                           //     of t), 0 = one sum that inflates the box, as FastWalk::entry does (C3 - 9 %)
+// Settled experiments, each measured in r03 (profiles/r03_chunk_steps.txt) and kept as tools/ablate/rb_forks.patch, not here:
+// the margin as one box inflation instead of its two parts (C3 - 9 %), Sp by the largest component (- 3 %), the fixed c0
+// instead of the ray's own cone bound (- 1..2 %), no chunks put aside (- 3..8 %), no prefetch of the next round (- 2 %).
 // of the hit's error (21.4 |s| + 9.1 L) u L^2 / |a|, (11.2 |s| + 4.6 L) is how far the exact plane
 // point Q* = o + t* d can be from the triangle's box -- that part inflates the box --, (10.2 |s| + 4.6 L) is |t^ - t*|, which
 // only moves the hit along the ray.  4 u of kChunkKS are for the slab arithmetic done on the uninflated box (chunk_child).
@@ -717,13 +679,9 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 // bounds, 5.42 u L^2 / |a^| <= 0.05, is the host's business where it can be (rb_bvh.cpp pack_fac) and this test elsewhere.
 constexpr float kChunkFMax = 1.5e5f;
 constexpr float kChunkKS = 24.0f * 5.9604645e-8f * 1.01f;
-#if RB_CHUNK_SPLIT
 constexpr float kChunkKP = 12.0f * 5.9604645e-8f * 1.01f;   // across
 constexpr float kChunkKT = 11.0f * 5.9604645e-8f * 1.01f;   // along
 constexpr float kChunkKD = 16.0f * 5.9604645e-8f * 1.01f;   // along, the relative part: 4 u t^ (t^ |d| <= |s| + 2.1 L), |d| = 1 +- 4 u, in units of Sp
-#else
-constexpr float kChunkKF = 27.0f * 5.9604645e-8f * 1.01f;   // FastWalk's margin
-#endif
 constexpr uint32_t kChunkWaveLds = 64u * 32u + 64u * 8u + 128u * 4u;  // per wave: ray records, best keys, unit table
 constexpr unsigned long long kChunkNoHit = 0x60AD78EC00000000ull;     // (bits of 1e20f) << 32: shader.wgsl:283-290
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -747,7 +705,6 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
     if (exact && !(tmax >= fmaxf(tmin, 0.0f))) return false;   // the reference does not enter this node
     // the bound of L^2 / |a^| this ray needs below the child
-#if RB_CHUNK_CONT
     // |a| = N |cos(d, n)| >= N lb for every triangle below, lb = the cone's lower bound of |cos| for THIS ray: the bound
     // (L^2 / N) / (0.95 lb) -- the stored one, made for |cos| >= c0, times c0 / lb -- up to the determinant floor,
     // which holds whatever the angle (all zeros = no cone: lb <= 0; tan = -1 = nothing below: the floor of nothing)
@@ -755,21 +712,12 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float cap = __uint_as_float(fac & 0xFFFF0000u);
     const float fl = __uint_as_float(fac << 16) * (kFastGrazeCos * 1.00001f) * __builtin_amdgcn_rcpf(lb);
     const float f = (lb > 1e-6f && fl < cap) ? fl : cap;   // NaN -> cap
-#else
-    // the determinant floor if it may graze a triangle there
-    const float f = cone_admits_grazing(d, cone) ? __uint_as_float(fac & 0xFFFF0000u) : __uint_as_float(fac << 16);
-#endif
     // Sp >= |o - v0| + L / 2 for every triangle below (E7's L terms are less than half its |s| terms): farthest corner
     // (v_sqrt_f32 is within 1 ulp) + half the box's extents
     const float mx = max_abs(a.x, b.x), my = max_abs(a.y, b.y), mz = max_abs(a.z, b.z);
-#if RB_CHUNK_SP == 0
     const float sp_ = 1.001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz))) +
                       0.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
-#else   // the corner's distance by its largest component: within sqrt(3), three instructions instead of eight
-    const float sp_ = 1.7321f * fmaxf(fmaxf(mx, my), mz) + 0.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));
-#endif
     const float ix = fabsf(inv.x), iy = fabsf(inv.y), iz = fabsf(inv.z);
-#if RB_CHUNK_SPLIT
     // Q* = o + t* d, the exact plane point of an accepted hit, lies on the ray within mm of the triangle's box, so the ray's
     // line passes the box inflated by mm at parameters [tn, tf] that hold t*; what is reported, t^, is within dt of t*, has to
     // be positive and, for the winner, no larger than the best t so far
@@ -780,14 +728,6 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fx), __builtin_fmaf(mm, iy, fy)), __builtin_fmaf(mm, iz, fz));
     order = tn;
     return !(tf < tn) && !(tf < -dt) && !(tn - dt > best_t);
-#else
-    const float sp0 = sp_ + 1.5f * (((b.x - a.x) + (b.y - a.y)) + (b.z - a.z));               // section 4.1's Sp: + 2 extents
-    const float mm = (f <= kChunkFMax) ? sp0 * __builtin_fmaf(kChunkKF, f, kChunkKS) : 1e30f;   // NaN -> 1e30
-    const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
-    const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fx), __builtin_fmaf(mm, iy, fy)), __builtin_fmaf(mm, iz, fz));
-    order = tn;
-    return !(tf < fmaxf(tn, 0.0f)) && !(tn > best_t);
-#endif
 }
 
 // cur is an internal node: descend into the nearer child that is entered, remember the other.  False when the walk is complete.
@@ -833,7 +773,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;
     const uint32_t sample_base = p.first_pass * p.samples_per_pass;
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
-    uint32_t* const stack = &s_stack[tid];
+    uint32_t* const stack = stack_column(s_stack, tid);
     Tally<STATS> tl;
     // this wave's corner of LDS behind the traversal stacks
     unsigned char* const wl = reinterpret_cast<unsigned char*>(s_stack + p.stack_depth * kTraceBlock) + (tid >> 6) * kChunkWaveLds;
@@ -844,18 +784,17 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
     uint32_t state = IDLE;
     uint32_t item = 0, cur = 0;
-    [[maybe_unused]] uint32_t pend = kChunkNone;   // RB_CHUNK_DEFER: the chunk this lane has put aside (cur == kChunkNone: nothing else left to walk)
+    uint32_t pend = kChunkNone;   // the chunk this lane has put aside (cur == kChunkNone: nothing else left to walk)
     ItemQueue iq(p, total_items);
     Path pt;
     pt.depth = 0;
     f3 inv = mk(0, 0, 0);
     unsigned long long key = kChunkNoHit;
     int sp = 0;
-    // RB_CHUNK_DEFER: a lane whose walk arrives at a chunk while it holds none aside keeps the chunk for the next leaf
+    // a lane whose walk arrives at a chunk while it holds none aside keeps the chunk for the next leaf
     // phase and goes on with the subtree it had put aside, so it takes part in twice as many node passes between two
     // waits (the best t it culls with is then one chunk behind: never wrong, rarely wasteful -- few chunk visits hit)
     auto set_aside = [&]() {
-#if RB_CHUNK_DEFER
         if (state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) != 0u && pend == kChunkNone) {
             pend = cur;
             if (sp == 0) {
@@ -865,7 +804,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                 cur = stack[sp * kTraceBlock];
             }
         }
-#endif
     };
 
     for (;;) {
@@ -911,10 +849,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
             if (n == 0u || (it > 0 && n < (uint32_t)RB_CHUNK_NODE_LANES)) break;
             if (at_node) {
                 if (!chunk_node_step<STATS>(p, stack, kTraceBlock, pt.o, pt.d, inv, __uint_as_float((uint32_t)(key >> 32)), cur, sp, tl)) {
-#if RB_CHUNK_DEFER
                     if (pend != kChunkNone) cur = kChunkNone;   // nothing left to walk, one chunk still to be tested
                     else
-#endif
                     state = FINISH;
                 }
                 set_aside();
@@ -924,11 +860,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
         // ---- (4) leaves: pool the (ray, chunk) pairs of the lanes that hold a chunk, 16 lanes per pair
         {
             const bool lf = state == TRAV && cur != kChunkNone && (cur & kChunkLeaf) != 0u;   // waits at a chunk
-#if RB_CHUNK_DEFER
             const bool lp = state == TRAV && pend != kChunkNone;                              // holds one aside
-#else
-            const bool lp = false;
-#endif
             const unsigned long long m = __ballot(lf), mp = __ballot(lp);
             const uint32_t n_pend = (uint32_t)__popcll(mp), n_units = n_pend + (uint32_t)__popcll(m);
             const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && cur != kChunkNone && !lf));
@@ -970,20 +902,11 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                     r.c = cc[pos];
                     return r;
                 };
-#if RB_CHUNK_PIPE
                 Round nx = fetch(0u);
-#endif
-#ifndef RB_CHUNK_UNROLL
-#define RB_CHUNK_UNROLL 1
-#endif
-#pragma unroll RB_CHUNK_UNROLL
+#pragma unroll 1
                 for (uint32_t g0 = 0; g0 < n_units; g0 += kPairsPerRound) {
-#if RB_CHUNK_PIPE
                     const Round r = nx;
                     if (g0 + kPairsPerRound < n_units) nx = fetch(g0 + kPairsPerRound);
-#else
-                    const Round r = fetch(g0);
-#endif
                     if constexpr (STATS) tl.tris += r.valid ? 1u : 0u;
                     float u, v;
                     const float t = isect_triangle(mk(r.r0.x, r.r0.y, r.r0.z), mk(r.r1.x, r.r1.y, r.r1.z), mk(r.a.x, r.a.y, r.a.z),
@@ -1054,17 +977,8 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
 #ifndef RB_FAST_KEEP
 #define RB_FAST_KEEP 32
 #endif
-#ifndef RB_FAST_LEAF_LANES
-#define RB_FAST_LEAF_LANES 32   // issue a leaf step once this many lanes wait at a leaf ...
-#endif
-#ifndef RB_FAST_NODE_LANES
-#define RB_FAST_NODE_LANES 16   // ... or fewer than this many are at inner nodes
-#endif
 #ifndef RB_FAST_NODE_STEPS
 #define RB_FAST_NODE_STEPS 2
-#endif
-#ifndef RB_SPH_NODE_STEPS
-#define RB_SPH_NODE_STEPS 2
 #endif
 #ifndef RB_FAST_WAVES
 #define RB_FAST_WAVES 4
@@ -1073,66 +987,15 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
 template <bool STATS>
 struct TriangleWalkPolicy {
     static constexpr int kNodeSteps = RB_FAST_NODE_STEPS;
-    static constexpr uint32_t kKinds = 4u;   // node / leaf of the library's tree, node / leaf chunk of the second pass
     FastWalk<STATS> w;
     DEV uint32_t kind() const { return w.kind(); }
     DEV bool step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.step(p, stack, kTraceBlock, tl); }
     DEV void init(const KParams& p) { w.begin(p, mk(0, 0, 0), mk(0, 0, 1)); }
     DEV void begin(const KParams& p, const Path& pt, uint32_t*, Tally<STATS>&) { w.begin(p, pt.o, pt.d); }
-    DEV bool at_leaf() const { return w.at_leaf(); }
-    DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.node_step(p, stack, kTraceBlock, tl); }
-    DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) { return w.leaf_step(p, stack, kTraceBlock, tl); }
     DEV bool finish(const KParams& p, Path& pt, uint32_t* stack, Tally<STATS>& tl) {
         return segment_finish<STATS>(p, pt, w.h, stack, kTraceBlock, tl);
     }
 };
-// ... and the sphere tree (scenes with more than 64 spheres, BASELINE C4; in the per-segment form a
-// wavefront walked it with 16 % of its lanes busy), between segment_pre (ground, the at most
-// single-node triangle list) and segment_post (lights, shading).  Used when there is no multi-node
-// triangle tree to walk as well.
-template <bool STATS>
-struct SphereWalkPolicy {
-    static constexpr int kNodeSteps = RB_SPH_NODE_STEPS;
-    static constexpr uint32_t kKinds = 2u;
-    DEV uint32_t kind() const { return w.at_leaf() ? 1u : 0u; }
-    DEV bool step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) {
-        return w.at_leaf() ? leaf_step(p, stack, tl) : node_step(p, stack, tl);
-    }
-    SphereWalk w;
-    TriHit th;
-    SegState st;
-    DEV void init(const KParams& p) {
-        w.begin(p, mk(0, 0, 0), mk(0, 0, 1), 1.0f, 1e20f);
-        th.hit = false;
-        th.t = 1e20f;
-        th.u = th.v = 0.0f;
-        th.slot = 0u;
-        st.closest_t = 1e20f;
-        st.kind = K_NONE;
-        st.uvx = st.uvy = 0.0f;
-        st.use_tex = st.tri_won_a = false;
-    }
-    DEV void begin(const KParams& p0, const Path& pt, uint32_t* stack, Tally<STATS>& tl) {
-        const KParams& p = fresh_params(p0);
-        th = intersect_bvh<STATS>(p, pt.o, pt.d, stack, kTraceBlock, tl);
-        st = segment_pre<STATS>(p, pt, th, tl);
-        w.begin(p, pt.o, pt.d, dot(pt.d, pt.d), st.closest_t);
-    }
-    DEV bool at_leaf() const { return w.at_leaf(); }
-    DEV bool node_step(const KParams& p, uint32_t* stack, Tally<STATS>&) { return w.node_step(p, stack, kTraceBlock); }
-    DEV bool leaf_step(const KParams& p, uint32_t* stack, Tally<STATS>& tl) {
-        unsigned long long* n_tested = nullptr;
-        if constexpr (STATS) n_tested = &tl.spheres;
-        return w.leaf_step(p, stack, kTraceBlock, n_tested);
-    }
-    DEV bool finish(const KParams& p, Path& pt, uint32_t*, Tally<STATS>& tl) {
-        float closest_t = st.closest_t;
-        uint32_t sphere_idx = 0xFFFFFFFFu;
-        w.result(closest_t, sphere_idx);
-        return segment_post<STATS>(fresh_params(p), pt, th, st, closest_t, sphere_idx, tl);
-    }
-};
-
 template <bool STATS, class Walk>
 DEV void trace_stepped(const KParams& p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
@@ -1145,7 +1008,7 @@ DEV void trace_stepped(const KParams& p) {
     const uint32_t total_items = tiles_x * tiles_y * S * 64u;
     const uint32_t sample_base = p.first_pass * p.samples_per_pass;
     float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
-    uint32_t* const stack = &s_stack[tid];
+    uint32_t* const stack = stack_column(s_stack, tid);
     Tally<STATS> tl;
 
     enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
@@ -1181,46 +1044,23 @@ DEV void trace_stepped(const KParams& p) {
             state = TRAV;
         }
 
-        // ---- (3) walk.  Every pass is either a node step for all lanes at an inner node or a leaf
-        // step for all lanes at a leaf -- whichever has enough lanes to be worth issuing (a lane
-        // reaches a leaf only every ~6 nodes, so waiting for ALL lanes to reach one would leave the
-        // node loop 20 % occupied).  At least one pass per outer iteration, then on while enough lanes
-        // are still walking.
-        if constexpr (Walk::kKinds > 2u) {
-            // four kinds of step (FastWalk: the library's tree, then the second pass over the reference tree): every
-            // pass runs the kind most lanes are waiting for, node kinds a few steps per vote
-            for (;;) {
-                const uint32_t k = state == TRAV ? w.kind() : 4u;
-                const uint32_t n0 = (uint32_t)__popcll(__ballot(k == 0u)), n1 = (uint32_t)__popcll(__ballot(k == 1u)),
-                               n2 = (uint32_t)__popcll(__ballot(k == 2u)), n3 = (uint32_t)__popcll(__ballot(k == 3u));
-                uint32_t pick = 0u, best = n0;
-                if (n1 > best) { pick = 1u; best = n1; }
-                if (n2 > best) { pick = 2u; best = n2; }
-                if (n3 > best) { pick = 3u; best = n3; }
-                if (best == 0u) break;
-                if (k == pick) {
-                    if (!w.step(p, stack, tl)) state = FINISH;
-                    if ((pick & 1u) == 0u)   // node kinds: a lane reaches a leaf only every few nodes
-                        for (int extra = 1; extra < Walk::kNodeSteps; ++extra)
-                            if (state == TRAV && w.kind() == pick && !w.step(p, stack, tl)) state = FINISH;
-                }
-                if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
-            }
-        } else
+        // ---- (3) walk: four kinds of step (FastWalk: node / leaf of the library's tree, then node / leaf chunk of the second
+        // pass over the reference tree); every pass runs the kind most lanes are waiting for, node kinds a few steps per
+        // vote (a lane reaches a leaf only every few nodes), then on while enough lanes are still walking
         for (;;) {
-            const bool at_node = state == TRAV && !w.at_leaf();
-            const bool at_leaf = state == TRAV && w.at_leaf();
-            const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-            if (n_leaf >= (uint32_t)RB_FAST_LEAF_LANES || n_node < (uint32_t)RB_FAST_NODE_LANES) {
-                if (at_leaf && !w.leaf_step(p, stack, tl)) state = FINISH;
-                if (n_leaf == 0u && at_node && !w.node_step(p, stack, tl)) state = FINISH;
-            } else {
-                if (at_node) {
-                    if (!w.node_step(p, stack, tl)) state = FINISH;
-                    // a lane reaches a leaf only every ~6 nodes: take more than one step per vote
+            const uint32_t k = state == TRAV ? w.kind() : 4u;
+            const uint32_t n0 = (uint32_t)__popcll(__ballot(k == 0u)), n1 = (uint32_t)__popcll(__ballot(k == 1u)),
+                           n2 = (uint32_t)__popcll(__ballot(k == 2u)), n3 = (uint32_t)__popcll(__ballot(k == 3u));
+            uint32_t pick = 0u, best = n0;
+            if (n1 > best) { pick = 1u; best = n1; }
+            if (n2 > best) { pick = 2u; best = n2; }
+            if (n3 > best) { pick = 3u; best = n3; }
+            if (best == 0u) break;
+            if (k == pick) {
+                if (!w.step(p, stack, tl)) state = FINISH;
+                if ((pick & 1u) == 0u)
                     for (int extra = 1; extra < Walk::kNodeSteps; ++extra)
-                        if (state == TRAV && !w.at_leaf() && !w.node_step(p, stack, tl)) state = FINISH;
-                }
+                        if (state == TRAV && w.kind() == pick && !w.step(p, stack, tl)) state = FINISH;
             }
             if ((uint32_t)__popcll(__ballot(state == TRAV)) < (uint32_t)RB_FAST_KEEP) break;
         }
@@ -1244,9 +1084,307 @@ template <bool STATS>
 __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const KParams p) {
     trace_stepped<STATS, TriangleWalkPolicy<STATS>>(p);
 }
+
+// ===================================================== kernel: SPHERES ====
+// Scenes with more than 64 spheres and no multi-node triangle tree (BASELINE C4: 10^6 spheres).  The reference scans every
+// sphere on every segment (shader.wgsl:574-586); the library walks its own tree (rb_internal.hpp SphereNode; built on the
+// device, rb_build.hip) between segment_pre (ground, the at most single-node triangle list) and segment_post (lights,
+// shading), with the two shapes of work of k_trace_chunk:
+//   lane = RAY for the tree: every lane walks its own ray down the two-box nodes, nearer child first, a child skipped only
+//     when no sphere below it can be REPORTED hit nearer than the best t (sphere_child, rb_device_shade.hpp);
+//   lane = SPHERE for the leaves: the (ray, leaf) pairs of all 64 lanes are pooled, every round 64 / kSphLeaf of them are
+//     tested by kSphLeaf lanes each -- one sphere per lane, the leaf's 16-byte {centre, radius} records read as consecutive
+//     bytes, the ray from LDS -- in two steps: the reference's discriminant for every lane (same operations, same bits:
+//     `disc < 0` is the reference's own early return), and only the survivors, compacted over the rounds into one list, go
+//     through the whole intersect_sphere (sqrt, divisions), 64 at a time.  A hit goes to its ray's best key with one LDS
+//     atomic min on (t bits) << 32 | original index: the key starts at (closest t of the earlier categories) << 32, so an
+//     equal t never displaces the ground or a triangle, and among spheres the lexicographic minimum is the linear scan's
+//     winner (strict `t < closest` in index order).
+// r03's form (every lane its own node and its own <= 4-sphere leaf: 8 L1 accesses per sphere test, 46 % of the lanes busy,
+// 42 % of the wave cycles waiting) made 4.48 G segments/s on C4.
+#ifndef RB_SPH_WAVES
+#define RB_SPH_WAVES 5
+#endif
+#ifndef RB_SPH_NODE_LANES
+#define RB_SPH_NODE_LANES 32
+#endif
+#ifndef RB_SPH_NODE_STEPS
+#define RB_SPH_NODE_STEPS 5
+#endif
+#ifndef RB_SPH_LEAF_LANES
+#define RB_SPH_LEAF_LANES 8
+#endif
+#ifndef RB_SPH_FINISH_LANES
+#define RB_SPH_FINISH_LANES 32
+#endif
+#ifdef RB_SPH_PROFILE
+__device__ unsigned long long g_sph_prof[16];
+#define SPH_PROF(i, v) prof[i] += (v)
+#else
+#define SPH_PROF(i, v)
+#endif
+constexpr uint32_t kSphWaveLds = 64u * 32u + 64u * 8u + 64u * 4u + 128u * 4u + 128u * 4u;   // per wave: ray records, best keys, a = d.d, units, survivors
+constexpr uint32_t kSphNone = 0xFFFFFFFFu;
+
 template <bool STATS>
-__global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_sph(const KParams p) {
-    trace_stepped<STATS, SphereWalkPolicy<STATS>>(p);
+__global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t width = p.u.width;
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t tiles_y = (p.local_rows + 7u) / 8u;
+    const uint32_t S = p.n_passes * p.samples_per_pass;
+    const uint32_t total_items = tiles_x * tiles_y * S * 64u;
+    const uint32_t sample_base = p.first_pass * p.samples_per_pass;
+    float4* __restrict__ colors = reinterpret_cast<float4*>(p.colors);
+    uint32_t* const stack = stack_column(s_stack, tid);
+    Tally<STATS> tl;
+    // this wave's corner of LDS behind the traversal stacks
+    unsigned char* const wl = reinterpret_cast<unsigned char*>(s_stack + p.stack_depth * kTraceBlock) + (tid >> 6) * kSphWaveLds;
+    lds_v4f* const rayrec = (lds_v4f*)wl;                           // [64][2]: {o, leaf put aside}, {d, leaf stood at}
+    lds_u64* const best = (lds_u64*)(wl + 64u * 32u);               // [64]: (t bits) << 32 | sphere index
+    typedef __attribute__((address_space(3))) float lds_f32;
+    lds_f32* const ray_a = (lds_f32*)(wl + 64u * 40u);              // [64]: d . d
+    lds_u32* const units = (lds_u32*)(wl + 64u * 44u);              // [128]: ray lane (| 64: the leaf it stands at) of every pooled (ray, leaf) pair
+    lds_u32* const cands = (lds_u32*)(wl + 64u * 44u + 128u * 4u);  // [128]: pair << 4 | sphere of the pair's leaf: discriminant >= 0
+
+    enum : uint32_t { IDLE = 0, BEGIN = 1, TRAV = 2, FINISH = 3 };
+    uint32_t state = IDLE;
+    uint32_t item = 0, cur = kSphNone, pend = kSphNone;
+    ItemQueue iq(p, total_items);
+    Path pt;
+    pt.depth = 0;
+    TriHit th;
+    th.hit = false;
+    th.t = 1e20f;
+    th.u = th.v = 0.0f;
+    th.slot = 0u;
+    SegState st;
+    st.closest_t = 1e20f;
+    st.kind = K_NONE;
+    st.uvx = st.uvy = 0.0f;
+    st.use_tex = st.tri_won_a = false;
+    f3 inv = mk(0, 0, 0);
+    float aa = 1.0f, rs = 1.0f;
+    unsigned long long key = 0ull;
+    int sp = 0;
+    // a lane whose walk arrives at a leaf while it holds none aside keeps the leaf for the next leaf phase and goes on with
+    // the subtree it had put aside (its best t is then one leaf behind: never wrong)
+#ifdef RB_SPH_PROFILE
+    unsigned long long prof[16] = {0};
+#endif
+    auto set_aside = [&]() {
+        if (state == TRAV && cur != kSphNone && (cur & 0x80000000u) != 0u && pend == kSphNone) {
+            pend = cur;
+            if (sp == 0) {
+                cur = kSphNone;
+            } else {
+                sp--;
+                cur = stack[sp * kTraceBlock];
+            }
+        }
+    };
+
+    for (;;) {
+        // ---- (1) hand items to idle lanes
+        iq.refill(fresh_params(p), lane, total_items, S, tiles_x, sample_base, [&] { return state == IDLE; },
+                  [&](uint32_t it, uint32_t x, uint32_t y, uint32_t sample_hash) {
+                      start_path_hashed(fresh_params(p), x, y, y * width + x, sample_hash, pt);
+                      item = it;
+                      if (p.u.max_depth > 0u) {
+                          state = BEGIN;
+                      } else {
+                          colors[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                          tl.paths++;
+                      }
+                  });
+        if (__ballot(state != IDLE) == 0ull) {
+            if (iq.drained()) break;
+            continue;
+        }
+
+        SPH_PROF(0, 1);
+        { const uint32_t nb = (uint32_t)__popcll(__ballot(state == BEGIN)); if (nb) { SPH_PROF(1, 1); SPH_PROF(2, nb); } }
+        // ---- (2) start of a segment: ground and the triangle list (shader.wgsl:552-571), then the root of the sphere tree
+        if (state == BEGIN) {
+            const KParams& fp = fresh_params(p);
+            th = intersect_bvh<STATS, false>(fp, pt.o, pt.d, stack, kTraceBlock, tl);
+            st = segment_pre<STATS>(fp, pt, th, tl);
+            // (1 / d only steers the walk: the hardware's reciprocal, within 1 ulp; the margin of sphere_child allows for it)
+            inv = mk(__builtin_amdgcn_rcpf(pt.d.x), __builtin_amdgcn_rcpf(pt.d.y), __builtin_amdgcn_rcpf(pt.d.z));
+            aa = dot(pt.d, pt.d);
+            rs = 1.001f * __builtin_amdgcn_rsqf(aa);
+            key = (unsigned long long)__float_as_uint(st.closest_t) << 32;
+            cur = fp.sph_root;
+            pend = kSphNone;
+            sp = 0;
+            state = TRAV;
+            set_aside();
+        }
+
+        // ---- (3) tree: a few node steps while enough lanes are at a node
+#pragma unroll 1
+        for (int it = 0; it < RB_SPH_NODE_STEPS; ++it) {
+            const bool at_node = state == TRAV && cur != kSphNone && (cur & 0x80000000u) == 0u;
+            const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
+            if (n == 0u || (it > 0 && n < (uint32_t)RB_SPH_NODE_LANES)) break;
+            SPH_PROF(3, 1); SPH_PROF(4, n);
+            if (at_node) {
+                const cf4p q = (cf4p)p.sph_nodes + (size_t)cur * 4u;
+                const v4f l0 = q[0], l1 = q[1], r0 = q[2], r1 = q[3];
+                const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
+                const float best_t = __uint_as_float((uint32_t)(key >> 32));
+                float kl, kr;
+                const bool vl = sphere_child(l0, l1, pt.o, inv, rs, best_t, kl), vr = sphere_child(r0, r1, pt.o, inv, rs, best_t, kr);
+                if (vl && vr) {
+                    const bool left_first = !(kr < kl);
+                    stack[sp * kTraceBlock] = left_first ? rref : lref;
+                    sp++;
+                    cur = left_first ? lref : rref;
+                } else if (vl || vr) {
+                    cur = vl ? lref : rref;
+                } else if (sp != 0) {
+                    sp--;
+                    cur = stack[sp * kTraceBlock];
+                } else if (pend != kSphNone) {
+                    cur = kSphNone;   // nothing left to walk, one leaf still to be tested
+                } else {
+                    state = FINISH;
+                }
+                set_aside();
+            }
+        }
+
+        // ---- (4) leaves: pool the (ray, leaf) pairs of the lanes that hold a leaf, kSphLeaf lanes per pair
+        {
+            const bool lf = state == TRAV && cur != kSphNone && (cur & 0x80000000u) != 0u;   // stands at a leaf
+            const bool lp = state == TRAV && pend != kSphNone;                               // holds one aside
+            const unsigned long long m = __ballot(lf), mp = __ballot(lp);
+            const uint32_t n_pend = (uint32_t)__popcll(mp), n_units = n_pend + (uint32_t)__popcll(m);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && cur != kSphNone && !lf));
+            if (n_units != 0u && (n_units >= (uint32_t)RB_SPH_LEAF_LANES || n_node == 0u)) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                SPH_PROF(5, 1); SPH_PROF(6, n_units); SPH_PROF(7, (n_units + 64u / kSphLeaf - 1u) / (64u / kSphLeaf));
+                if (lp) units[(uint32_t)__popcll(mp & below)] = lane;
+                if (lf) units[n_pend + (uint32_t)__popcll(m & below)] = lane | 64u;
+                if (lf || lp) {
+                    const v4f r0 = {pt.o.x, pt.o.y, pt.o.z, __uint_as_float(pend)}, r1 = {pt.d.x, pt.d.y, pt.d.z, __uint_as_float(cur)};
+                    rayrec[lane * 2u] = r0;
+                    rayrec[lane * 2u + 1u] = r1;
+                    best[lane] = key;
+                    ray_a[lane] = aa;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const cf4p leafs = (cf4p)p.sph_leaf;
+                const RB_CONST uint32_t* ids = cptr(p.sph_id);
+                constexpr uint32_t kPairsPerRound = 64u / kSphLeaf;
+                // the survivors of the discriminant, 64 at a time (or what is left): the whole intersect_sphere
+                uint32_t n_cand = 0u;
+                auto flush = [&](uint32_t k) {
+                    SPH_PROF(8, 1); SPH_PROF(9, k);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < k) {
+                        const uint32_t c = cands[n_cand - k + lane], g = c >> 4, e = units[g], rl = e & 63u;
+                        const v4f r0 = rayrec[rl * 2u], r1 = rayrec[rl * 2u + 1u];
+                        const uint32_t pos = sph_leaf_first(__float_as_uint((e & 64u) ? r1.w : r0.w)) + (c & 15u);
+                        const v4f cr = leafs[pos];
+                        const uint32_t id = ids[pos];
+                        const float t = isect_sphere(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), ray_a[rl], mk(cr.x, cr.y, cr.z), cr.w);
+                        if (t > 0.001f) {
+                            const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | id;
+                            __hip_atomic_fetch_min(&best[rl], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                    n_cand -= k;
+                };
+                struct Round {
+                    v4f r0, r1, cr;
+                    float a;
+                    uint32_t tag;   // pair << 4 | sphere
+                    bool valid;
+                };
+                auto fetch = [&](uint32_t g0) {
+                    Round r;
+                    const uint32_t g = g0 + lane / kSphLeaf;
+                    const bool ok = g < n_units;
+                    const uint32_t e = units[ok ? g : 0u], rl = e & 63u;
+                    r.r0 = rayrec[rl * 2u];
+                    r.r1 = rayrec[rl * 2u + 1u];
+                    r.a = ray_a[rl];
+                    const uint32_t ref = __float_as_uint((e & 64u) ? r.r1.w : r.r0.w), j = lane & (kSphLeaf - 1u);
+                    r.valid = ok && j < sph_leaf_count(ref);
+                    r.cr = leafs[sph_leaf_first(ref) + (r.valid ? j : 0u)];
+                    r.tag = (g << 4) | j;
+                    return r;
+                };
+                Round nx = fetch(0u);
+#pragma unroll 1
+                for (uint32_t g0 = 0; g0 < n_units; g0 += kPairsPerRound) {
+                    const Round r = nx;
+                    if (g0 + kPairsPerRound < n_units) nx = fetch(g0 + kPairsPerRound);
+                    if constexpr (STATS) tl.spheres += r.valid ? 1u : 0u;
+                    // shader.wgsl:194-199, the operations of isect_sphere up to its first return
+                    const f3 oc = mk(r.r0.x, r.r0.y, r.r0.z) - mk(r.cr.x, r.cr.y, r.cr.z), d = mk(r.r1.x, r.r1.y, r.r1.z);
+                    const float half_b = dot(oc, d);
+                    const float c = dot(oc, oc) - r.cr.w * r.cr.w;
+                    const float disc = half_b * half_b - r.a * c;
+                    const bool cand = r.valid && !(disc < 0.0f);
+                    const unsigned long long cm = __ballot(cand);
+                    if (cm != 0ull) {
+                        if (cand) cands[n_cand + (uint32_t)__popcll(cm & below)] = r.tag;
+                        n_cand += (uint32_t)__popcll(cm);
+                        if (n_cand >= 64u) flush(64u);
+                    }
+                }
+                if (n_cand != 0u) flush(n_cand);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lf || lp) {
+                    key = best[lane];
+                    pend = kSphNone;
+                    if (lf || cur == kSphNone) {   // the leaf the lane stood at is done, or there was nothing left to walk
+                        if (sp == 0) {
+                            state = FINISH;
+                        } else {
+                            sp--;
+                            cur = stack[sp * kTraceBlock];
+                        }
+                    }
+                    set_aside();
+                }
+            }
+        }
+
+        // ---- (5) finished walks: lights, the winner's record, shading (shader.wgsl:590-660), next ray
+        {
+            const uint32_t n_fin = (uint32_t)__popcll(__ballot(state == FINISH));
+            const uint32_t n_trav = (uint32_t)__popcll(__ballot(state == TRAV));
+            if (n_fin != 0u && (n_fin >= (uint32_t)RB_SPH_FINISH_LANES || n_trav == 0u)) { SPH_PROF(10, 1); SPH_PROF(11, n_fin); }
+            if (n_fin != 0u && (n_fin >= (uint32_t)RB_SPH_FINISH_LANES || n_trav == 0u) && state == FINISH) {
+                float closest_t = st.closest_t;
+                uint32_t sphere_idx = 0xFFFFFFFFu;
+                if (key < ((unsigned long long)__float_as_uint(st.closest_t) << 32)) {   // a sphere strictly nearer than the earlier categories
+                    closest_t = __uint_as_float((uint32_t)(key >> 32));
+                    sphere_idx = (uint32_t)key;
+                }
+                const bool alive = segment_post<STATS>(fresh_params(p), pt, th, st, closest_t, sphere_idx, tl);
+                if (alive) {
+                    state = BEGIN;
+                } else {
+                    store_color(colors, item, pt.color);
+                    tl.paths++;
+                    state = IDLE;
+                }
+            }
+        }
+    }
+    flush_tally<STATS>(tl, p.counters);
+#ifdef RB_SPH_PROFILE
+    if (lane == 0u) for (int i = 0; i < 12; i++) atomicAdd(&g_sph_prof[i], prof[i]);
+#endif
 }
 
 // Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,
@@ -1532,7 +1670,7 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
     p.cam = host_cam(p.u);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LaunchInfo li{};
-    const size_t lds = sizeof(uint32_t) * p.stack_depth * 256u;
+    const size_t lds = (size_t)kStackEntryBytes * p.stack_depth * 256u;
     li.lds_bytes = lds;
     if (kernel == RB_KERNEL_PIXEL) {
         const uint32_t tiles_x = (p.u.width + 15u) / 16u, tiles_y = (p.local_rows + 15u) / 16u;
@@ -1578,13 +1716,15 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
         static const char* const names[] = {"k_trace", "k_trace_bvh", "k_trace_bvh_lds", "k_trace_fast", "k_trace_sph", "k_trace_chunk"};
         li.kernel_name = names[v];
         li.block = v == BVH_LDS ? 1024u : kTraceBlock;
-        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : v == CHUNK ? lds + (kTraceBlock / 64u) * kChunkWaveLds : lds;
+        li.lds_bytes = v == BVH_LDS ? lds * 4u + scene_lds : v == CHUNK ? lds + (kTraceBlock / 64u) * kChunkWaveLds
+                                     : v == SPH ? lds + (kTraceBlock / 64u) * kSphWaveLds : lds;
         // residency (registers): k_trace 6 waves/SIMD, the stepped walks 4
         // (a launch of one or two samples per pixel -- the progressive iterator's -- leaves a wavefront of the full grid a
         // few hundred items: with half the grid each regenerates paths for longer and the tail is shorter: 1080p, 1 spp,
         // 0.72 instead of 0.80 ms per frame)
         const uint32_t dense = (items >= (uint64_t)device_cu_count_cached() * 8u * 4u * 1024u) ? 8u : 4u;
-        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : (v == FAST || v == SPH) ? 4u : v == CHUNK ? (uint32_t)RB_CHUNK_WAVES : dense;
+        const uint32_t blocks_per_cu = v == BVH_LDS ? 1u : p.blocks_per_cu ? p.blocks_per_cu : v == FAST ? 4u : v == SPH ? (uint32_t)RB_SPH_WAVES
+                                                                                                   : v == CHUNK ? (uint32_t)RB_CHUNK_WAVES : dense;
         li.grid = persistent_blocks(items, li.block, blocks_per_cu);
         if (li.grid == 0) return 0;
         // batch: the queue word sustains about 90 M atomics/s chip-wide, which 64-item reservations reach at 5-6 G
@@ -1634,8 +1774,8 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
         const dim3 grid(li.grid), block(li.block);
         switch (v) {
             case SPH:
-                if (stats) hipLaunchKernelGGL(k_trace_sph<true>, grid, block, lds, stream, q);
-                else hipLaunchKernelGGL(k_trace_sph<false>, grid, block, lds, stream, q);
+                if (stats) hipLaunchKernelGGL(k_trace_sph<true>, grid, block, li.lds_bytes, stream, q);
+                else hipLaunchKernelGGL(k_trace_sph<false>, grid, block, li.lds_bytes, stream, q);
                 break;
             case CHUNK:
                 if (stats) hipLaunchKernelGGL(k_trace_chunk<true>, grid, block, li.lds_bytes, stream, q);
@@ -1772,6 +1912,20 @@ double measure_l1_gather(size_t table_bytes, uint32_t rounds) {
     (void)hipFree(table);
     (void)hipFree(sink);
     return best;
+}
+
+int debug_sph_profile(unsigned long long* out16, int reset) {
+#ifdef RB_SPH_PROFILE
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sph_prof), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_sph_prof), z, sizeof(z));
+    }
+    return (int)e;
+#else
+    (void)out16; (void)reset;
+    return -1;
+#endif
 }
 
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream_) {

@@ -205,6 +205,8 @@ int gather_init_group(Gather& g, const std::vector<int>& devices, bool peer_copy
     return 0;
 }
 
+int gather_available(std::string& why) { return rccl_ok(why) ? 0 : 1; }
+
 int gather_unique_id(uint8_t* id128, std::string& why) {
     if (!rccl_ok(why)) return 1;
     NcclId id;

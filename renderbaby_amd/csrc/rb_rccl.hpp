@@ -39,6 +39,7 @@ struct Gather {
 
 // all return 0 or a non-zero status with `why` set
 int gather_init_group(Gather& g, const std::vector<int>& devices, bool peer_copy, std::string& why);
+int gather_available(std::string& why);   // can RCCL be loaded here?  (dlopen + dlsym only: no id, no socket, no thread)
 int gather_unique_id(uint8_t* id128, std::string& why);
 int gather_init_rank(Gather& g, int device, const uint8_t* id128, uint32_t rank, uint32_t nranks, std::string& why);
 int gather_group(Gather& g, const std::vector<GatherSource>& parts, uint32_t width, uint32_t height, uint32_t padded_rows,

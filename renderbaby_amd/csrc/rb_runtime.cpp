@@ -143,8 +143,10 @@ struct rb_engine {
     DevBuf<float> sph_leaf;
     DevBuf<uint32_t> sph_id;
     uint32_t sph_root = 0, sph_depth = 0;
-    float sph_bmin[3] = {0, 0, 0}, sph_bmax[3] = {0, 0, 0};
     bool sph_bvh = false;
+    bool stack_depth_covers = true;    // set with KParams::stack_depth: every walk in use fits its LDS column
+    const char* sph_builder = "";      // "device-lbvh" | "host-median" | "" (linear scan)
+    float sph_build_ms = 0.0f;
     DevBuf<float> colors;            // RB_KERNEL_STREAM: float4 per (pixel, sample) of one launch chunk
     uint64_t color_budget = 0;       // bytes `colors` may take (0 = ask the device at the next dispatch)
     uint32_t bvh_stack = 0;          // traversal-stack entries the current tree needs
@@ -348,13 +350,39 @@ int prep_materials(rb_engine* e, rb_material* first, size_t stride, size_t n) {
 }
 
 // Spheres beyond kSphereBvhThreshold get the library's own acceleration structure; the
-// reference's linear scan (shader.wgsl:574-586) stays the rule for small counts.
+// reference's linear scan (shader.wgsl:574-586) stays the rule for small counts.  From kSphereDeviceBuildMin spheres
+// up the tree is made on the device from the copy that is already there (rb_build.hip: Morton order + LBVH over
+// kSphLeaf-sphere leaves; 10^6 spheres in a few milliseconds where the host's median splits take 0.1 s);
+// RB_FLAG_SPHERE_TREE_HOST / RB_FLAG_SPHERE_TREE_DEVICE force either builder.  The frame does not depend on which one ran.
 int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
     e->sph_bvh = false;
-    if (n <= rb::kSphereBvhThreshold || n >= (1u << 28) || (e->opt.flags & RB_FLAG_NO_SPHERE_BVH)) return RB_OK;
+    e->sph_builder = "";
+    if (n <= rb::kSphereBvhThreshold || n >= (1u << 27) || (e->opt.flags & RB_FLAG_NO_SPHERE_BVH)) return RB_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool force_host = (e->opt.flags & RB_FLAG_SPHERE_TREE_HOST) != 0u, force_dev = (e->opt.flags & RB_FLAG_SPHERE_TREE_DEVICE) != 0u;
+    if (!force_host && (force_dev || n >= rb::kSphereDeviceBuildMin)) {
+        const size_t n_leaf = (n + rb::kSphLeaf - 1) / rb::kSphLeaf;
+        HIP_TRY(e, e->sph_nodes.resize(std::max<size_t>(n_leaf - 1, 1)));
+        HIP_TRY(e, e->sph_leaf.resize(n * 4));
+        HIP_TRY(e, e->sph_id.resize(n));
+        rb::DeviceSphereTreeInfo info{};
+        const int rc = rb::device_sphere_bvh_build(e->spheres.ptr, static_cast<uint32_t>(n), e->sph_nodes.ptr, e->sph_leaf.ptr, e->sph_id.ptr,
+                                                   &info, e->stream);
+        if (rc) return fail(e, RB_ERR_DEVICE, "device sphere tree build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (info.depth <= rb::kStackDepth) {
+            e->sph_root = info.root;
+            e->sph_depth = info.depth;
+            e->sph_bvh = true;
+            e->sph_builder = "device-lbvh";
+            e->sph_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            return RB_OK;
+        }
+        // (a Morton tree deeper than the LDS stack -- heavily clustered centres: the host's median splits are balanced)
+    }
     std::vector<rb::SphereNode> nodes;
     std::vector<uint32_t> order;
-    rb::sphere_bvh_build(s, n, nodes, order, &e->sph_root, &e->sph_depth, e->sph_bmin, e->sph_bmax);
+    float bmin[3], bmax[3];
+    rb::sphere_bvh_build(s, n, nodes, order, &e->sph_root, &e->sph_depth, bmin, bmax);
     if (e->sph_depth > rb::kStackDepth) return RB_OK;  // degenerate input: keep the linear scan
     std::vector<float> leaf(n * 4);
     for (size_t j = 0; j < n; ++j) {
@@ -370,6 +398,8 @@ int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
     if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));  // the vectors above are locals
     e->sph_bvh = true;
+    e->sph_builder = "host-median";
+    e->sph_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return RB_OK;
 }
 
@@ -734,15 +764,17 @@ rb::KParams make_params(rb_engine* e, uint32_t first_pass, uint32_t n_passes, in
     p.sph_leaf = e->sph_leaf.ptr;
     p.sph_id = e->sph_id.ptr;
     p.sph_root = e->sph_root;
-    for (int i = 0; i < 3; ++i) {
-        p.sph_bmin[i] = e->sph_bmin[i];
-        p.sph_bmax[i] = e->sph_bmax[i];
-    }
     // a single-node tree is walked without a stack (rb_kernels.hip, intersect_bvh)
     p.stack_depth = (p.u.bvh_node_count <= 1u) ? 0u : std::max(e->bvh_stack, 1u);
     if (use_sph_bvh) p.stack_depth = std::max(p.stack_depth, e->sph_depth);
     if (use_fast) p.stack_depth = std::max(p.stack_depth, std::min(e->fast_depth, rb::kStackDepth));
-    if (use_chunk) p.stack_depth = std::max(use_sph_bvh ? e->sph_depth : 1u, e->chunk_depth + 1u);
+    // (max with what is there already: with no_leaf_stepping the launch falls to the per-segment kernel, which walks the
+    // CALLER's tree and needs bvh_stack entries -- the chunk tree can be shallower where it prunes empty subtrees)
+    if (use_chunk) p.stack_depth = std::max(p.stack_depth, e->chunk_depth + 1u);
+    // every walk a launch can run must fit the column it shares with the others (rb_internal.hpp, kStackEntryBytes)
+    e->stack_depth_covers = p.stack_depth <= rb::kStackDepth && (p.u.bvh_node_count <= 1u || p.stack_depth >= e->bvh_stack) &&
+                            (!use_sph_bvh || p.stack_depth >= e->sph_depth) && (!use_chunk || p.stack_depth >= e->chunk_depth + 1u) &&
+                            (!use_fast || p.stack_depth >= std::min(e->fast_depth, rb::kStackDepth));
     p.stack_overflow = e->stack_overflow.ptr;
     p.blocks_per_cu = e->opt._reserved[0];
     // the caller's reservation size: a multiple of 64 items, at most 4096 (the launcher's own range; beyond it the
@@ -846,6 +878,7 @@ int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int 
         const uint32_t n = std::min(chunk, n_passes - done);
         // the first chunk resumes `src`; later chunks of the same group continue in `dst`
         rb::KParams p = make_params(e, first_pass + done, n, done == 0 ? src : dst, dst);
+        if (!e->stack_depth_covers) return fail(e, RB_ERR_DEVICE, "internal: a traversal is deeper than its LDS stack column (%u entries)", p.stack_depth);
         rb::LaunchInfo li{};
         // per-chunk timing events (first 256 chunks of a group; later ones only count in the total)
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -1231,6 +1264,15 @@ rb_engine* rb_create_multi(const rb_config* cfg, const rb_options* opt_in, const
     }
     rb_engine* out = g.release();
     return out;
+}
+
+int rb_comm_available(void) {
+    std::string why;
+    if (rb::gather_available(why)) {
+        g_create_error = why;
+        return RB_ERR_DEVICE;
+    }
+    return RB_OK;
 }
 
 int rb_comm_unique_id(uint8_t id_out[RB_COMM_ID_BYTES]) {
@@ -1680,6 +1722,12 @@ const char* rb_fast_bvh_builder(const rb_engine* e, float* build_ms) {
     return (e && e->fast_ready) ? e->fast_builder : "";
 }
 
+const char* rb_sphere_tree_builder(const rb_engine* e, float* build_ms) {
+    if (e && is_group(e)) e = e->parts[0].get();
+    if (build_ms) *build_ms = (e && e->sph_bvh) ? e->sph_build_ms : 0.0f;
+    return (e && e->sph_bvh) ? e->sph_builder : "";
+}
+
 int rb_device_name(int device, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0) return RB_ERR_NULL_ARGUMENT;
     hipDeviceProp_t prop;
@@ -1719,7 +1767,7 @@ int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uin
     return (rc || st != hipSuccess) ? RB_ERR_DEVICE : RB_OK;
 }
 
-// Debug hook for tests/test_gpu_math.py: device /, sqrt, normalize, u32->f32, min/max, dot.
+// Test aid (host only): the chunked walk's tree for a mesh and a caller tree, with its invariants checked.
 int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh_node* nodes, size_t n_nodes, const uint32_t* indices,
                         size_t n_indices, uint64_t out6[6]) {
     if (!tris || !nodes || !indices || !out6) return RB_ERR_NULL_ARGUMENT;
@@ -1754,6 +1802,14 @@ int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_
     return *accesses_per_s > 0.0 ? RB_OK : RB_ERR_DEVICE;
 }
 
+int rb_debug_walk_profile(uint64_t out16[16], int reset) {
+    if (!out16) return RB_ERR_NULL_ARGUMENT;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    if (hipDeviceSynchronize() != hipSuccess) return RB_ERR_DEVICE;
+    return rb::debug_sph_profile(reinterpret_cast<unsigned long long*>(out16), reset) == 0 ? RB_OK : RB_ERR_DEVICE;
+}
+
+// Debug hook for tests/test_gpu_parity.py: device /, sqrt, normalize, u32->f32, min/max, dot.
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n) {
     if (!a || !b || !out8n) return RB_ERR_NULL_ARGUMENT;
     float *da = nullptr, *db = nullptr, *dout = nullptr;

@@ -87,11 +87,14 @@ class ShardedRenderer:
             # RCCL path came up, otherwise all fall back to the torch.distributed gather below
             import torch.distributed as dist
             # ncclCommInitRank is collective: a rank whose librccl does not load must not leave the others waiting
-            # inside it.  Every rank first probes RCCL on its own (ncclGetUniqueId loads the library and is not
-            # collective), the ranks agree on the outcome, and only then the communicator is made.
+            # inside it.  Every rank first probes RCCL on its own (rb_comm_available: dlopen + dlsym, no id -- an id made
+            # on a rank that then discards it would leave a bootstrap socket and a waiting thread behind), the ranks
+            # agree on the outcome, rank 0 alone makes the id, and only then the communicator is made.
             ok, why, my_id = 1, "", None
             try:
-                my_id = Engine.comm_unique_id()
+                Engine.comm_available()
+                if rank == 0:
+                    my_id = Engine.comm_unique_id()
             except Exception as ex:   # librccl not loadable on this rank
                 ok, why = 0, str(ex)
             flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")

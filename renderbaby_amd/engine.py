@@ -172,7 +172,8 @@ class Engine:
                  passes_per_launch=0, kernel=abi.KERNEL_DEFAULT, stats=False, blocks_per_cu=0, color_budget_mib=0,
                  no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False,
                  device_lbvh=False, reference_walk=False, host_bvh=False, devices=None, gather_peer_copy=False,
-                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0, chunk_walk=False):
+                 no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0, chunk_walk=False,
+                 sphere_tree=None):
         """``devices`` (list of HIP ordinals): one handle over several devices of this process
         (rb_create_multi): rows sharded in stripes, one RCCL gather per delivered frame."""
         self._lib = load()
@@ -191,7 +192,8 @@ class Engine:
             | (abi.FLAG_DEVICE_LBVH if device_lbvh else 0) | (abi.FLAG_REFERENCE_WALK if reference_walk else 0) \
             | (abi.FLAG_HOST_BVH if host_bvh else 0) | (abi.FLAG_GATHER_PEER_COPY if gather_peer_copy else 0) \
             | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0) | (abi.FLAG_SKIP_NEAR_DEGENERATE if skip_near_degenerate else 0) \
-            | (abi.FLAG_CHUNK_WALK if chunk_walk else 0)
+            | (abi.FLAG_CHUNK_WALK if chunk_walk else 0) \
+            | {None: 0, "host": abi.FLAG_SPHERE_TREE_HOST, "device": abi.FLAG_SPHERE_TREE_DEVICE}[sphere_tree]
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[2] = queue_batch   # items a wave reserves per queue atomic (0 = the launcher's choice)
@@ -246,6 +248,13 @@ class Engine:
         return w, h
 
     # ---- one process per device: the stripes are gathered to rank 0 inside rb_render / rb_iter_next
+    @staticmethod
+    def comm_available():
+        """Raises unless this process can load RCCL (no communicator id is made: rb_comm_available)."""
+        rc = load().rb_comm_available()
+        if rc:
+            raise RenderError(rc, (load().rb_last_error(None) or b"").decode())
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
@@ -348,6 +357,12 @@ class Engine:
         """("host-sah" | "device-lbvh" | "", build milliseconds) of the tree RB_FLAG_FAST_BVH walks."""
         ms = C.c_float()
         name = (self._lib.rb_fast_bvh_builder(self._h, C.byref(ms)) or b"").decode()
+        return name, ms.value
+
+    def sphere_tree_builder(self):
+        """("device-lbvh" | "host-median" | "", build milliseconds) of the library's sphere tree (> 64 spheres)."""
+        ms = C.c_float()
+        name = (self._lib.rb_sphere_tree_builder(self._h, C.byref(ms)) or b"").decode()
         return name, ms.value
 
     def last_dispatch_ms(self):

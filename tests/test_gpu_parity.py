@@ -230,8 +230,12 @@ def test_sphere_bvh_matches_the_linear_scan(n, extent, size):
     # exactly the linear scan's winner (oracle = reference algorithm, O(N) per segment)
     s = scenes.spheres_scene(n=n, width=size, height=size, spp=2, max_depth=5, extent=extent)
     o_acc, _, o_rgba, o_st = _oracle.render(s)
-    for kw in (dict(), dict(no_sphere_bvh=True)):
-        frame, acc, st = _hip(s, abi.KERNEL_STREAM, stats=False, **kw)
+    # the tree from either builder (device: Morton order + LBVH; host: median splits), walked by the pooled kernel and per
+    # segment, and the GPU's own linear scan
+    for kw in (dict(), dict(sphere_tree="host"), dict(sphere_tree="device"), dict(sphere_tree="device", no_leaf_stepping=True),
+               dict(sphere_tree="host", kernel=abi.KERNEL_QUEUE), dict(no_sphere_bvh=True)):
+        kernel = kw.pop("kernel", abi.KERNEL_STREAM)
+        frame, acc, st = _hip(s, kernel, stats=False, **kw)
         bad = np.argwhere(acc.view(np.uint32) != o_acc.view(np.uint32))
         assert len(bad) == 0, (kw, len(bad), bad[:4])
         assert np.array_equal(frame.pixels, o_rgba)

@@ -43,7 +43,7 @@ def parity():
 
 
 def speed(which):
-    from tests import _refscenes
+    from renderbaby_amd import refscenes as _refscenes
     mk = {"c3": lambda: scenes.mesh_c3().with_params(spp=int(os.environ.get("SPP", "16"))),
           "lamp": lambda: _refscenes.ref_lamp(spp=int(os.environ.get("SPP", "8"))),
           "c5": lambda: scenes.mesh_c5().with_params(spp=int(os.environ.get("SPP", "4"))),
@@ -90,7 +90,7 @@ def speed(which):
 
 def prof(which):
     """With a -DRB_CHUNK_PROFILE=1|2 build (RB_LIBRARY_PATH): the raw counter slots of one instrumented pass."""
-    from tests import _refscenes
+    from renderbaby_amd import refscenes as _refscenes
     mk = {"c3": lambda: scenes.mesh_c3().with_params(spp=4), "lamp": lambda: _refscenes.ref_lamp(spp=2),
           "c5": lambda: scenes.mesh_c5().with_params(spp=1)}
     for name in which:

@@ -132,7 +132,9 @@ def variants(scene):
               ("fast", dict(fast_bvh=True)),
               ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
     if len(scene.spheres) > 64:
-        v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True))]
+        v += [("sph-perseg", dict(no_leaf_stepping=True)), ("scan", dict(no_sphere_bvh=True)),
+              ("sph-host", dict(sphere_tree="host")), ("sph-device", dict(sphere_tree="device")),
+              ("sph-device-perseg", dict(sphere_tree="device", no_leaf_stepping=True))]
     only = os.environ.get("FUZZ_VARIANTS")   # e.g. FUZZ_VARIANTS=default,chunk-small-batches: a focused campaign
     if only:
         v = [x for x in v if x[0] in only.split(",")]

@@ -6,7 +6,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from renderbaby_amd import Engine, RenderConfig, scenes
-from tests import _refscenes
+from renderbaby_amd import refscenes as _refscenes
 
 cases = [("reference lamp scene 2056x2056, 16 spp, depth 5", _refscenes.ref_lamp(spp=16)),
          ("C3 mesh 50176 tris 1920x1080, 64 spp, depth 5", scenes.mesh_c3().with_params(spp=64)),

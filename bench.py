@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "lamp"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--kernel", type=int, default=0)
-    ap.add_argument("--stripe-rows", type=int, default=1)
+    ap.add_argument("--stripe-rows", type=int, default=8,
+                    help="rows per stripe of the N > 1 split; 8 = the library's default (the kernel tile's height: profiles/r04_shard_rehearsal.txt)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-stats", action="store_true", help="skip the instrumented pass (roofline.algorithmic = null)")
     ap.add_argument("--skip-near-degenerate", action="store_true", help="RB_FLAG_SKIP_NEAR_DEGENERATE (the one unproved mode)")
@@ -210,19 +211,36 @@ def end_to_end(scene, wkw, kernel, device):
     eng.dispatch(0, 0)                       # prepared triangles + the library's own levels of the tree, nothing traced
     eng.sync()
     out["tree_build_ms"] = (time.perf_counter() - t) * 1e3
+    out["sphere_tree"], out["sphere_tree_build_ms"] = eng.sphere_tree_builder()   # (inside upload_ms: rb_update builds it)
+    t = time.perf_counter()
+    eng.reserve(scene.total_samples)         # the stream kernels' colour buffer (lazily allocated otherwise: up to 4 GiB of hipMalloc)
+    out["alloc_ms"] = (time.perf_counter() - t) * 1e3
     t = time.perf_counter()
     eng.clear()
     eng.dispatch(0, scene.total_samples)
     eng.sync()
     out["render_ms"] = (time.perf_counter() - t) * 1e3
+    # read-back into pageable memory (a buffer the host has touched before, as a frame buffer that is reused would be) and
+    # into page-locked memory (rb_host_alloc: a DMA on the copy stream)
+    import ctypes as C2
+    frame = np.zeros((scene.height, scene.width, 4), dtype=np.uint8)
     t = time.perf_counter()
-    frame = eng.read_rgba()
+    eng._check(eng._lib.rb_read_rgba(eng._h, frame.ctypes.data))
     out["readback_ms"] = (time.perf_counter() - t) * 1e3
+    from renderbaby_amd.engine import PinnedFrame
+    hf = PinnedFrame(scene.width, scene.height)
+    t = time.perf_counter()
+    eng._check(eng._lib.rb_read_rgba(eng._h, hf.array.ctypes.data))
+    out["readback_pinned_ms"] = (time.perf_counter() - t) * 1e3
+    same = bool(np.array_equal(hf.array, frame))
+    hf.free()
     eng.close()
-    out["total_ms"] = sum(out[k] for k in ("reference_tree_build_ms", "upload_ms", "tree_build_ms", "render_ms", "readback_ms"))
-    out["note"] = ("wall clock on a fresh engine; reference_tree_build = the caller's median-split tree over the scene's triangles "
-                   "(the reference rebuilds it per render, scene_engine_adapter.rs:435-440), tree_build = prepared triangles + the "
-                   "library's own levels; benchmark.rs:43-45 times the sum")
+    out["total_ms"] = sum(out[k] for k in ("reference_tree_build_ms", "upload_ms", "tree_build_ms", "alloc_ms", "render_ms", "readback_ms"))
+    out["note"] = ("wall clock on a fresh engine, right after the timed steps (the device is warm); each piece synchronised: reference_tree_build = "
+                   "the caller's median-split tree over the scene's triangles (the reference rebuilds it per render, "
+                   "scene_engine_adapter.rs:435-440), upload = create + rb_update (with the sphere tree, if any), tree_build = prepared "
+                   "triangles + the library's own levels, alloc = the colour buffer, readback = pageable destination (pinned beside it: "
+                   "%s); benchmark.rs:43-45 times the sum" % ("same bytes" if same else "DIFFERENT BYTES"))
     return out, frame
 
 
@@ -404,9 +422,6 @@ def main():
             roof["measured_copy_peak"] = measured_copy_bandwidth(f"cuda:{local_rank}")  # GB/s, read + write
         except Exception:
             pass
-        cpu = None
-        if a.cpu_seconds > 0 and world == 1:
-            cpu = cpu_baseline(scene, a.cpu_seconds)
         # ---- the frame itself: a checksum every N must reproduce (the sharded frame is the single-GPU frame by construction)
         import zlib
         import numpy as np
@@ -429,6 +444,10 @@ def main():
         if world == 1 and not a.no_end_to_end:
             e2e, e2e_frame = end_to_end(scene, wkw, a.kernel, local_rank)
             e2e["frame_equals_timed_frame"] = bool(fr is not None and np.array_equal(e2e_frame, fr))
+        # (the CPU leg last: the end_to_end leg above should find the device as the timed steps left it, not after 15 s of idling)
+        cpu = None
+        if a.cpu_seconds > 0 and world == 1:
+            cpu = cpu_baseline(scene, a.cpu_seconds)
         out = {
             "metric": "Msamples/s (ray-segments/s)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,

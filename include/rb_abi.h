@@ -211,7 +211,7 @@ typedef struct rb_options {
     int32_t device;             /* HIP device ordinal; -1 = current */
     uint32_t shard_rank;        /* this engine renders stripes s with s % shard_count == shard_rank */
     uint32_t shard_count;       /* 0 or 1 = whole frame */
-    uint32_t stripe_rows;       /* rows per stripe; 0 = default (16) */
+    uint32_t stripe_rows;       /* rows per stripe; 0 = default (8: the height of a kernel tile) */
     uint32_t passes_per_launch; /* samples per pixel folded into one kernel launch; 0 = default */
     uint32_t kernel;            /* RB_KERNEL_* ; 0 = default */
     uint32_t flags;             /* RB_FLAG_* */
@@ -232,7 +232,7 @@ enum {
     RB_FLAG_STATS = 1u, /* count nodes/tris/spheres/lights per segment (slower) */
     RB_FLAG_NO_SPHERE_BVH = 2u, /* always use the reference's linear sphere scan (shader.wgsl:574-586) */
     RB_FLAG_SPHERE_TREE_HOST = 2048u,   /* more than 64 spheres: build the library's sphere tree on the host (median splits) ... */
-    RB_FLAG_SPHERE_TREE_DEVICE = 4096u, /* ... or on the device (Morton order + LBVH) whatever the count; by default the device
+    RB_FLAG_SPHERE_TREE_DEVICE = 4096u, /* ... or on the device (the same splits, a segmented sort per level) whatever the count; by default the device
                                            builds it from 1024 spheres up.  The frame does not depend on the builder. */
     RB_FLAG_FAST_BVH = 4u, /* multi-node meshes: walk the library's own tree over the triangles (culling, near-first) plus
                               a second pass over the caller's tree for hits reported from near-zero determinants, and accept
@@ -373,6 +373,10 @@ int rb_clear(rb_engine* e);
  * engine's stream (dispatch_compute_progressive, gpu_wrapper.rs:365-400,
  * without the per-pass host sync). */
 int rb_dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes);
+/* Optional: everything a dispatch of n_passes passes would set up lazily -- the prepared triangles and the library's own
+ * levels of the tree (as rb_dispatch(e, 0, 0) does), and the stream kernels' colour buffer (up to 4 GiB of device memory) --
+ * without tracing anything.  A host that times its first frame calls this first and does not time hipMalloc. */
+int rb_reserve(rb_engine* e, uint32_t n_passes);
 /* Wait for the engine's stream. */
 int rb_sync(rb_engine* e);
 /* Copy this engine's RGBA8 rows (mirrored, local stripe order) to the host. */
@@ -462,7 +466,7 @@ const char* rb_last_kernel_name(const rb_engine* e);
  * time of that build including its uploads. */
 const char* rb_fast_bvh_builder(const rb_engine* e, float* build_ms);
 
-/* Which builder produced the library's sphere tree (scenes with more than 64 spheres): "device-lbvh", "host-median", or
+/* Which builder produced the library's sphere tree (scenes with more than 64 spheres): "device-median", "host-median", or
  * "" when the engine scans (<= 64 spheres, RB_FLAG_NO_SPHERE_BVH).  Valid after the rb_update that brought the spheres.
  * `build_ms`, if not NULL, receives the wall time of that build including its uploads. */
 const char* rb_sphere_tree_builder(const rb_engine* e, float* build_ms);

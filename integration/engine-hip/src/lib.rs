@@ -64,7 +64,7 @@ fn frame_for(e: *mut ffi::RbEngine) -> Result<Frame> {
 #[derive(Default, Clone)]
 pub struct EngineOptions {
     pub devices: Vec<i32>,            // empty: the current device; several: one handle over all of them
-    pub stripe_rows: u32,             // rows per stripe of the row sharding (0 = 16)
+    pub stripe_rows: u32,             // rows per stripe of the row sharding (0 = 8)
     pub own_tree: bool,               // RB_FLAG_FAST_BVH: the library's tree for multi-node meshes (same frames)
     pub device_built_tree: bool,      // RB_FLAG_DEVICE_BVH
     pub passes_per_frame: u32,        // iterator: a frame every n samples (0 / 1 = every sample)

@@ -57,6 +57,7 @@ def load():
         "rb_get_size": (i32, [vp, P(u32), P(u32)]),
         "rb_clear": (i32, [vp]),
         "rb_dispatch": (i32, [vp, u32, u32]),
+        "rb_reserve": (i32, [vp, u32]),
         "rb_sync": (i32, [vp]),
         "rb_read_rgba": (i32, [vp, vp]),
         "rb_read_accumulation": (i32, [vp, vp]),
@@ -107,6 +108,6 @@ def source_fingerprint():
 
 EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_available", "rb_comm_unique_id", "rb_comm_init_rank", "rb_comm_info", "rb_destroy", "rb_update", "rb_render", "rb_render_config",
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_iter_set_passes_per_frame", "rb_last_error",
-           "rb_get_size", "rb_clear", "rb_dispatch", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
+           "rb_get_size", "rb_clear", "rb_dispatch", "rb_reserve", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
            "rb_device_rgba", "rb_host_alloc", "rb_host_free", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",
            "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_walk_profile", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_sphere_tree_builder", "rb_version", "rb_device_name"]

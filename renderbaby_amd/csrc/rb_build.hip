@@ -420,182 +420,201 @@ __global__ void k_ploc_finish(PlocClusters c, const uint32_t* __restrict__ bound
 
 inline size_t align256(size_t x) { return (x + 255u) & ~size_t(255); }
 
-// ---- The sphere tree (BASELINE C4: 10^6 spheres; rb_device_shade.hpp SphereWalk, rb_kernels.hip k_trace_sph) built on
-// the device: Morton order of the centres, leaves = kSphLeaf consecutive spheres of that order (one 16-byte {centre,
-// radius} record each, so the lanes that test a leaf read consecutive bytes), and the LBVH of this file over the leaves'
-// first keys.  The tree only steers the walk -- every candidate goes through the reference's intersect_sphere and ties
-// resolve by the original index -- so the frame is the same bits as with the host's median-split tree (rb_bvh.cpp), which
-// stays as the fallback (a tree deeper than the LDS stack) and as the checker (tests/test_gpu_sphere_tree.py).
-__global__ void __launch_bounds__(256) k_sph_bounds(const rb_sphere* __restrict__ spheres, uint32_t n, uint32_t* bounds) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const float inf = __builtin_inff();
-    float cn[3] = {inf, inf, inf}, cx[3] = {-inf, -inf, -inf};
-    if (i < n) {
-        const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)i * 6u];
-        cn[0] = cx[0] = cr.x; cn[1] = cx[1] = cr.y; cn[2] = cx[2] = cr.z;
-    }
-    for (int a = 0; a < 3; ++a) {
-        for (int off = 32; off > 0; off >>= 1) {
-            cn[a] = fminf(cn[a], __shfl_xor(cn[a], off, 64));
-            cx[a] = fmaxf(cx[a], __shfl_xor(cx[a], off, 64));
-        }
-    }
-    if ((threadIdx.x & 63u) == 0u) {
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&bounds[6 + a], f2ord(cn[a]));
-            atomicMax(&bounds[9 + a], f2ord(cx[a]));
-        }
-    }
+// ---- The sphere tree (BASELINE C4: 10^6 spheres; rb_internal.hpp SphereNode4, rb_device_shade.hpp sphere_node_step,
+// rb_kernels.hip k_trace_sph) built on the device: the host builder's median splits (rb_bvh.cpp), level by level.  The
+// spheres of level l's segment s are positions [s n / 2^l, (s + 1) n / 2^l) of the current order -- a complete tree, nothing
+// to store --; one pass per level finds every segment's longest axis (bounds of the centres), keys every sphere with
+// (segment, centre along that axis) and sorts: the halves of every segment are then the next level's segments.  Splitting
+// stops at the first level whose segments hold at most kSphLeaf spheres; two levels of splits make one 4-wide node.
+// (r04's first device builder -- Morton order, leaves of 16 consecutive spheres, an LBVH above them -- built in 7 ms and made
+// the walk test 2.4 times as many spheres as the median splits: 123 against 51 per segment on C4.)
+// The tree only steers the walk -- every candidate goes through the reference's intersect_sphere and ties resolve by the
+// original index -- so the frame is the same bits as with the host's tree, which stays as the fallback and the checker.
+__device__ __forceinline__ uint32_t ms_start(uint32_t s, uint32_t n, uint32_t l) { return (uint32_t)(((unsigned long long)s * n) >> l); }
+__device__ __forceinline__ uint32_t ms_segment(uint32_t i, uint32_t n, uint32_t l) {   // the s with ms_start(s) <= i < ms_start(s + 1)
+    return (uint32_t)(((((unsigned long long)i + 1ull) << l) - 1ull) / n);
 }
 
-__global__ void __launch_bounds__(256) k_sph_keys(const rb_sphere* __restrict__ spheres, uint32_t n, const uint32_t* __restrict__ bounds,
-                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ items) {
+__global__ void __launch_bounds__(256) k_ms_init(const rb_sphere* __restrict__ spheres, uint32_t n, float4* __restrict__ cen,
+                                                  uint32_t* __restrict__ items) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)i * 6u];
-    const float c[3] = {cr.x, cr.y, cr.z};
-    // one scale for the three axes (the largest extent): the cells are cubes, so a flat scene (C4: 200 x 20 x 200) is cut
-    // along its long axes first instead of into slabs a tenth as thick as they are wide
-    float ext = 0.0f;
-    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, ord2f(bounds[9 + k]) - ord2f(bounds[6 + k]));
-    uint32_t q[3];
-    for (int k = 0; k < 3; ++k) {
-        const float lo = ord2f(bounds[6 + k]);
-        float x = (ext > 0.0f) ? (c[k] - lo) / ext * 2097152.0f : 0.0f;
-        x = fminf(fmaxf(x, 0.0f), 2097151.0f);  // NaN -> 0
-        q[k] = static_cast<uint32_t>(x);
-    }
-    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    cen[i] = reinterpret_cast<const float4*>(spheres)[(size_t)i * 6u];   // {centre, radius}
     items[i] = i;
 }
 
-// one thread per sphere of the sorted order: its leaf record and original index; one thread per leaf: the leaf's box
-// (c -+ r in f32: what the walk's margin allows for, rb_device_shade.hpp kSphAbs) and first key
-__global__ void __launch_bounds__(256) k_sph_leaves(const rb_sphere* __restrict__ spheres, const uint32_t* __restrict__ items,
-                                                     const unsigned long long* __restrict__ keys, uint32_t n, uint32_t n_leaf,
-                                                     float4* __restrict__ leaf_out, uint32_t* __restrict__ id_out,
-                                                     float4* __restrict__ lmin, float4* __restrict__ lmax,
-                                                     unsigned long long* __restrict__ lkeys, uint32_t* __restrict__ ident) {
+// bounds of the centres per segment (ordered uints: [s][0..2] min, [s][3..5] max).  Large segments: one thread per
+// sphere, a wavefront that lies inside one segment reduces first; small ones (SMALL): one thread per segment.
+template <bool SMALL>
+__global__ void __launch_bounds__(256) k_ms_bounds(const float4* __restrict__ cen, const uint32_t* __restrict__ items, uint32_t n,
+                                                    uint32_t l, uint32_t* __restrict__ segb) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const float inf = __builtin_inff();
+    if constexpr (SMALL) {
+        if (i >= (1u << l)) return;
+        const uint32_t first = ms_start(i, n, l), end = ms_start(i + 1u, n, l);
+        float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+        for (uint32_t j = first; j < end; ++j) {
+            const float4 c = cen[items[j]];
+            mn[0] = fminf(mn[0], c.x); mn[1] = fminf(mn[1], c.y); mn[2] = fminf(mn[2], c.z);
+            mx[0] = fmaxf(mx[0], c.x); mx[1] = fmaxf(mx[1], c.y); mx[2] = fmaxf(mx[2], c.z);
+        }
+        for (int a = 0; a < 3; ++a) {
+            segb[i * 6u + a] = f2ord(mn[a]);
+            segb[i * 6u + 3u + a] = f2ord(mx[a]);
+        }
+    } else {
+        float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+        uint32_t s = 0xFFFFFFFFu;
+        if (i < n) {
+            const float4 c = cen[items[i]];
+            mn[0] = mx[0] = c.x; mn[1] = mx[1] = c.y; mn[2] = mx[2] = c.z;
+            s = ms_segment(i, n, l);
+        }
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        if (__ballot(s != s0) == 0ull) {   // the whole wavefront in one segment (or past the end)
+            if (s0 == 0xFFFFFFFFu) return;
+            for (int a = 0; a < 3; ++a)
+                for (int off = 32; off > 0; off >>= 1) {
+                    mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+                    mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+                }
+            if ((threadIdx.x & 63u) == 0u)
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(&segb[s0 * 6u + a], f2ord(mn[a]));
+                    atomicMax(&segb[s0 * 6u + 3u + a], f2ord(mx[a]));
+                }
+        } else if (i < n) {
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&segb[s * 6u + a], f2ord(mn[a]));
+                atomicMax(&segb[s * 6u + 3u + a], f2ord(mx[a]));
+            }
+        }
+    }
+}
+
+// key = segment << 32 | centre along the segment's longest axis (the host builder's rule: x if it is the strictly longest,
+// else y if longer than z, else z); the axis of every segment is kept for the nodes' visiting order
+__global__ void __launch_bounds__(256) k_ms_keys(const float4* __restrict__ cen, const uint32_t* __restrict__ items, uint32_t n, uint32_t l,
+                                                  const uint32_t* __restrict__ segb, unsigned long long* __restrict__ keys,
+                                                  unsigned char* __restrict__ axes_l) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = ms_segment(i, n, l);
+    const float ex = ord2f(segb[s * 6u + 3u]) - ord2f(segb[s * 6u]), ey = ord2f(segb[s * 6u + 4u]) - ord2f(segb[s * 6u + 1u]),
+                ez = ord2f(segb[s * 6u + 5u]) - ord2f(segb[s * 6u + 2u]);
+    const uint32_t axis = (ex > ey && ex > ez) ? 0u : ((ey > ez) ? 1u : 2u);
+    const float4 c = cen[items[i]];
+    const float v = axis == 0u ? c.x : axis == 1u ? c.y : c.z;
+    keys[i] = ((unsigned long long)s << 32) | f2ord(v);
+    if (i == ms_start(s, n, l)) axes_l[s] = (unsigned char)axis;
+}
+
+// the final order: leaf records, original indices, and the box of every leaf (heap index 2^L - 1 + leaf; c -+ r in f32: what
+// the walk's margin allows for, rb_device_shade.hpp kSphAbs)
+__global__ void __launch_bounds__(256) k_ms_leaves(const float4* __restrict__ cen, const uint32_t* __restrict__ items, uint32_t n, uint32_t L,
+                                                    float4* __restrict__ leaf_out, uint32_t* __restrict__ id_out, float4* __restrict__ hmin,
+                                                    float4* __restrict__ hmax) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
         const uint32_t id = items[i];
-        leaf_out[i] = reinterpret_cast<const float4*>(spheres)[(size_t)id * 6u];
+        leaf_out[i] = cen[id];
         id_out[i] = id;
     }
-    if (i < n_leaf) {
-        const uint32_t first = i * kSphLeaf, end = (first + kSphLeaf < n) ? first + kSphLeaf : n;
+    if (i < (1u << L)) {
+        const uint32_t first = ms_start(i, n, L), end = ms_start(i + 1u, n, L);
         const float inf = __builtin_inff();
         float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
         for (uint32_t j = first; j < end; ++j) {
-            const float4 cr = reinterpret_cast<const float4*>(spheres)[(size_t)items[j] * 6u];
-            const float c[3] = {cr.x, cr.y, cr.z};
-            for (int a = 0; a < 3; ++a) {
-                mn[a] = fminf(mn[a], c[a] - cr.w);
-                mx[a] = fmaxf(mx[a], c[a] + cr.w);
-            }
+            const float4 c = cen[items[j]];
+            mn[0] = fminf(mn[0], c.x - c.w); mn[1] = fminf(mn[1], c.y - c.w); mn[2] = fminf(mn[2], c.z - c.w);
+            mx[0] = fmaxf(mx[0], c.x + c.w); mx[1] = fmaxf(mx[1], c.y + c.w); mx[2] = fmaxf(mx[2], c.z + c.w);
         }
-        lmin[i] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-        lmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
-        lkeys[i] = keys[first];
-        ident[i] = i;
+        const uint32_t h = (1u << L) - 1u + i;
+        hmin[h] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        hmax[h] = make_float4(mx[0], mx[1], mx[2], 0.0f);
     }
 }
 
-// bottom-up boxes and heights over the leaves' LBVH (as k_lbvh_refit, every internal node a real node)
-__global__ void __launch_bounds__(256) k_sph_refit(uint32_t n_leaf, const float4* __restrict__ lmin, const float4* __restrict__ lmax,
-                                                    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                                                    const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent,
-                                                    uint32_t* flags, float4* nmin, float4* nmax) {
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    if (pos >= n_leaf) return;
-    uint32_t cur = leaf_parent[pos];
-    for (;;) {
-        __threadfence();
-        if (atomicAdd(&flags[cur], 1u) == 0u) return;  // the sibling subtree is not finished yet
-        __threadfence();
-        float4 lo[2], hi[2];
-        uint32_t hgt[2];
-        const uint32_t ch[2] = {left[cur], right[cur]};
-        for (int k = 0; k < 2; ++k) {
-            if (ch[k] & kLeafTag) {
-                lo[k] = lmin[ch[k] & ~kLeafTag];
-                hi[k] = lmax[ch[k] & ~kLeafTag];
-                hgt[k] = 0u;
-            } else {
-                lo[k] = nmin[ch[k]];  // written by another CU: the fence above has invalidated L1
-                hi[k] = nmax[ch[k]];
-                hgt[k] = __float_as_uint(hi[k].w);
-            }
-        }
-        const uint32_t h = (hgt[0] > hgt[1] ? hgt[0] : hgt[1]) + 1u;
-        nmin[cur] = make_float4(fminf(lo[0].x, lo[1].x), fminf(lo[0].y, lo[1].y), fminf(lo[0].z, lo[1].z), 0.0f);
-        nmax[cur] = make_float4(fmaxf(hi[0].x, hi[1].x), fmaxf(hi[0].y, hi[1].y), fmaxf(hi[0].z, hi[1].z), __uint_as_float(h));
-        if (cur == 0u) return;
-        cur = parent[cur];
-    }
+__global__ void __launch_bounds__(256) k_ms_up(uint32_t l, float4* __restrict__ hmin, float4* __restrict__ hmax) {   // level l from level l + 1
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= (1u << l)) return;
+    const uint32_t h = (1u << l) - 1u + s, c = (2u << l) - 1u + 2u * s;
+    const float4 a0 = hmin[c], a1 = hmax[c], b0 = hmin[c + 1u], b1 = hmax[c + 1u];
+    hmin[h] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
+    hmax[h] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
 }
 
-__device__ __forceinline__ uint32_t sph_leaf_ref(uint32_t leaf, uint32_t n) {
-    const uint32_t first = leaf * kSphLeaf, cnt = (n - first < kSphLeaf) ? n - first : kSphLeaf;
-    return kLeafTag | ((cnt - 1u) << 27) | first;
-}
+// node index of segment s of the even level l: the even levels back to back (1 + 4 + 16 + ... nodes before level l)
+__device__ __host__ __forceinline__ uint32_t ms_node_index(uint32_t l, uint32_t s) { return (uint32_t)((((1ull << l) - 1ull) / 3ull) + s); }
 
-__global__ void __launch_bounds__(256) k_sph_emit(uint32_t n, uint32_t n_leaf, const float4* __restrict__ lmin,
-                                                   const float4* __restrict__ lmax, const uint32_t* __restrict__ left,
-                                                   const uint32_t* __restrict__ right, const float4* __restrict__ nmin,
-                                                   const float4* __restrict__ nmax, SphereNode* __restrict__ nodes,
-                                                   DeviceSphereTreeInfo* info) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i + 1u < n_leaf) {
-        float4 o[4];
-        uint32_t ref[2];
-        const uint32_t ch[2] = {left[i], right[i]};
-        for (int k = 0; k < 2; ++k) {
-            if (ch[k] & kLeafTag) {
-                const uint32_t leaf = ch[k] & ~kLeafTag;
-                o[2 * k] = lmin[leaf];
-                o[2 * k + 1] = lmax[leaf];
-                ref[k] = sph_leaf_ref(leaf, n);
-            } else {
-                o[2 * k] = nmin[ch[k]];
-                o[2 * k + 1] = nmax[ch[k]];
-                ref[k] = ch[k];
-            }
+__global__ void __launch_bounds__(256) k_ms_emit(uint32_t n, uint32_t L, uint32_t l, const float4* __restrict__ hmin, const float4* __restrict__ hmax,
+                                                  const unsigned char* __restrict__ axes, SphereNode4* __restrict__ nodes) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= (1u << l)) return;
+    SphereNode4 nd{};
+    for (int k = 0; k < 4; ++k) nd.ref[k] = kSphNone;
+    auto child = [&](int k, uint32_t cl, uint32_t cs) {   // slot k = segment cs of level cl
+        const uint32_t h = (1u << cl) - 1u + cs;
+        const float4 lo = hmin[h], hi = hmax[h];
+        nd.lox[k] = lo.x; nd.loy[k] = lo.y; nd.loz[k] = lo.z;
+        nd.hix[k] = hi.x; nd.hiy[k] = hi.y; nd.hiz[k] = hi.z;
+        if (cl == L) {
+            const uint32_t first = ms_start(cs, n, L), cnt = ms_start(cs + 1u, n, L) - first;
+            nd.ref[k] = kLeafTag | ((cnt - 1u) << 27) | first;
+        } else {
+            nd.ref[k] = ms_node_index(cl, cs);
         }
-        SphereNode nd;
-        nd.lmin[0] = o[0].x; nd.lmin[1] = o[0].y; nd.lmin[2] = o[0].z; nd.left = ref[0];
-        nd.lmax[0] = o[1].x; nd.lmax[1] = o[1].y; nd.lmax[2] = o[1].z; nd.right = ref[1];
-        nd.rmin[0] = o[2].x; nd.rmin[1] = o[2].y; nd.rmin[2] = o[2].z; nd._pad0 = 0u;
-        nd.rmax[0] = o[3].x; nd.rmax[1] = o[3].y; nd.rmax[2] = o[3].z; nd._pad1 = 0u;
-        nodes[i] = nd;
+    };
+    // axes[] holds level 0's segment, then level 1's two, ...: level l starts at 2^l - 1
+    nd.axes = axes[(1u << l) - 1u + s];
+    if (l + 1u == L) {   // an odd number of levels: the last nodes have two children, the leaves
+        child(0, l + 1u, 2u * s);
+        child(2, l + 1u, 2u * s + 1u);
+    } else {
+        nd.axes |= ((uint32_t)axes[(2u << l) - 1u + 2u * s] << 2) | ((uint32_t)axes[(2u << l) - 1u + 2u * s + 1u] << 4);
+        for (uint32_t k = 0; k < 4u; ++k) child((int)k, l + 2u, 4u * s + k);
     }
-    if (i == 0u) {
-        info->root = n_leaf > 1u ? 0u : sph_leaf_ref(0u, n);
-        info->depth = n_leaf > 1u ? __float_as_uint(nmax[0].w) + 1u : 1u;   // entries the walk's stack can hold at once: <= internal levels
-    }
+    nodes[ms_node_index(l, s)] = nd;
 }
 
 }  // namespace
 
-int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode* nodes_out, float* leaf_out, uint32_t* id_out,
+// levels of median splits for n spheres: the first level whose segments hold at most kSphLeaf
+static uint32_t sphere_tree_levels(size_t n) {
+    uint32_t L = 0;
+    while (((n + (size_t(1) << L) - 1) >> L) > kSphLeaf) ++L;
+    return L;
+}
+size_t sphere_tree_node_capacity(size_t n) {
+    const uint32_t L = sphere_tree_levels(n);
+    size_t nodes = 0;
+    for (uint32_t l = 0; l < L; l += 2) nodes += size_t(1) << l;
+    return nodes ? nodes : 1;
+}
+
+int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode4* nodes_out, float* leaf_out, uint32_t* id_out,
                             DeviceSphereTreeInfo* info_out, void* stream_) {
     if (n == 0u || n >= (1u << 27)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using key_t = unsigned long long;
-    const uint32_t n_leaf = (n + kSphLeaf - 1u) / kSphLeaf;
+    const uint32_t L = sphere_tree_levels(n);   // leaves = the 2^L segments of level L, every one non-empty (n > kSphLeaf 2^(L-1) >= 2^L)
+    if (L == 0u) {   // one leaf (not reached through the runtime: it scans up to 64 spheres)
+        info_out->root = kLeafTag | ((n - 1u) << 27);
+        info_out->depth = 0;
+        info_out->n_nodes = 0;
+    }
     size_t sort_bytes = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<key_t*>(nullptr), static_cast<key_t*>(nullptr),
-                                             static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n, 0, 63, stream);
+                                             static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n, 0, 64, stream);
     if (e != hipSuccess) return static_cast<int>(e);
+    const size_t heap = size_t(2) << L;   // segments of levels 0 .. L: 2^(L+1) - 1
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-    const size_t o_keys_in = carve(sizeof(key_t) * n), o_keys = carve(sizeof(key_t) * n);
-    const size_t o_items_in = carve(4u * n), o_items = carve(4u * n);
-    const size_t o_lmin = carve(16u * n_leaf), o_lmax = carve(16u * n_leaf), o_nmin = carve(16u * n_leaf), o_nmax = carve(16u * n_leaf);
-    const size_t o_lkeys = carve(sizeof(key_t) * n_leaf), o_ident = carve(4u * n_leaf);
-    const size_t o_left = carve(4u * n_leaf), o_right = carve(4u * n_leaf), o_first = carve(4u * n_leaf), o_size = carve(4u * n_leaf);
-    const size_t o_parent = carve(4u * n_leaf), o_leafpar = carve(4u * n_leaf), o_flags = carve(4u * n_leaf);
-    const size_t o_bounds = carve(64), o_info = carve(sizeof(DeviceSphereTreeInfo)), o_sort = carve(sort_bytes);
+    const size_t o_keys_a = carve(sizeof(key_t) * n), o_keys_b = carve(sizeof(key_t) * n);
+    const size_t o_items_a = carve(4u * n), o_items_b = carve(4u * n), o_cen = carve(16u * size_t(n));
+    const size_t o_segb = carve(24u * (size_t(1) << (L ? L - 1u : 0u))), o_axes = carve(heap);
+    const size_t o_hmin = carve(16u * heap), o_hmax = carve(16u * heap), o_sort = carve(sort_bytes);
     char* base = nullptr;
     e = hipMalloc(reinterpret_cast<void**>(&base), off);
     if (e != hipSuccess) return static_cast<int>(e);
@@ -605,42 +624,41 @@ int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode* no
         (void)hipFree(base);
         return static_cast<int>(err);
     };
-    key_t* keys_in = reinterpret_cast<key_t*>(at(o_keys_in));
-    key_t* keys = reinterpret_cast<key_t*>(at(o_keys));
-    uint32_t* items_in = reinterpret_cast<uint32_t*>(at(o_items_in));
-    uint32_t* items = reinterpret_cast<uint32_t*>(at(o_items));
-    float4 *lmin = reinterpret_cast<float4*>(at(o_lmin)), *lmax = reinterpret_cast<float4*>(at(o_lmax));
-    float4 *nmin = reinterpret_cast<float4*>(at(o_nmin)), *nmax = reinterpret_cast<float4*>(at(o_nmax));
-    key_t* lkeys = reinterpret_cast<key_t*>(at(o_lkeys));
-    uint32_t* ident = reinterpret_cast<uint32_t*>(at(o_ident));
-    uint32_t *left = reinterpret_cast<uint32_t*>(at(o_left)), *right = reinterpret_cast<uint32_t*>(at(o_right));
-    uint32_t *rfirst = reinterpret_cast<uint32_t*>(at(o_first)), *rsize = reinterpret_cast<uint32_t*>(at(o_size));
-    uint32_t *parent = reinterpret_cast<uint32_t*>(at(o_parent)), *leafpar = reinterpret_cast<uint32_t*>(at(o_leafpar));
-    uint32_t* flags = reinterpret_cast<uint32_t*>(at(o_flags));
-    uint32_t* bounds = reinterpret_cast<uint32_t*>(at(o_bounds));
-    DeviceSphereTreeInfo* d_info = reinterpret_cast<DeviceSphereTreeInfo*>(at(o_info));
-    const uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u,
-                               0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    const dim3 grid((n + 255u) / 256u), lgrid((n_leaf + 255u) / 256u), block(256);
-    e = hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return done(e);
-    e = hipMemsetAsync(flags, 0, 4u * n_leaf, stream);
-    if (e != hipSuccess) return done(e);
-    hipLaunchKernelGGL(k_sph_bounds, grid, block, 0, stream, spheres, n, bounds);
-    hipLaunchKernelGGL(k_sph_keys, grid, block, 0, stream, spheres, n, bounds, keys_in, items_in);
-    e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_in, keys, items_in, items, n, 0, 63, stream);
-    if (e != hipSuccess) return done(e);
-    hipLaunchKernelGGL(k_sph_leaves, grid, block, 0, stream, spheres, items, keys, n, n_leaf, reinterpret_cast<float4*>(leaf_out),
-                       id_out, lmin, lmax, lkeys, ident);
-    if (n_leaf > 1u) {
-        hipLaunchKernelGGL(k_lbvh_hierarchy, lgrid, block, 0, stream, lkeys, n_leaf, left, right, rfirst, rsize, parent, leafpar);
-        hipLaunchKernelGGL(k_sph_refit, lgrid, block, 0, stream, n_leaf, lmin, lmax, left, right, parent, leafpar, flags, nmin, nmax);
+    key_t *keys_a = reinterpret_cast<key_t*>(at(o_keys_a)), *keys_b = reinterpret_cast<key_t*>(at(o_keys_b));
+    uint32_t *items = reinterpret_cast<uint32_t*>(at(o_items_a)), *items_b = reinterpret_cast<uint32_t*>(at(o_items_b));
+    float4* cen = reinterpret_cast<float4*>(at(o_cen));
+    uint32_t* segb = reinterpret_cast<uint32_t*>(at(o_segb));
+    unsigned char* axes = reinterpret_cast<unsigned char*>(at(o_axes));
+    float4 *hmin = reinterpret_cast<float4*>(at(o_hmin)), *hmax = reinterpret_cast<float4*>(at(o_hmax));
+    const dim3 grid((n + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(k_ms_init, grid, block, 0, stream, spheres, n, cen, items);
+    for (uint32_t l = 0; l < L; ++l) {
+        const uint32_t segs = 1u << l;
+        if (n / segs >= 256u) {   // (ordered uints: min starts at all ones, max at zero)
+            e = hipMemsetAsync(segb, 0, 24u * size_t(segs), stream);
+            if (e != hipSuccess) return done(e);
+            e = hipMemset2DAsync(segb, 24, 0xFF, 12, segs, stream);
+            if (e != hipSuccess) return done(e);
+            hipLaunchKernelGGL(k_ms_bounds<false>, grid, block, 0, stream, cen, items, n, l, segb);
+        } else {
+            hipLaunchKernelGGL(k_ms_bounds<true>, dim3((segs + 255u) / 256u), block, 0, stream, cen, items, n, l, segb);
+        }
+        hipLaunchKernelGGL(k_ms_keys, grid, block, 0, stream, cen, items, n, l, segb, keys_a, axes + (segs - 1u));
+        e = rocprim::radix_sort_pairs(at(o_sort), sort_bytes, keys_a, keys_b, items, items_b, n, 0, 32u + l, stream);
+        if (e != hipSuccess) return done(e);
+        std::swap(items, items_b);
     }
-    hipLaunchKernelGGL(k_sph_emit, lgrid, block, 0, stream, n, n_leaf, lmin, lmax, left, right, nmin, nmax, nodes_out, d_info);
+    hipLaunchKernelGGL(k_ms_leaves, grid, block, 0, stream, cen, items, n, L, reinterpret_cast<float4*>(leaf_out), id_out, hmin, hmax);
+    for (uint32_t l = L; l-- > 0;) hipLaunchKernelGGL(k_ms_up, dim3(((1u << l) + 255u) / 256u), block, 0, stream, l, hmin, hmax);
+    uint32_t levels4 = 0;
+    for (uint32_t l = 0; l < L; l += 2, ++levels4)
+        hipLaunchKernelGGL(k_ms_emit, dim3(((1u << l) + 255u) / 256u), block, 0, stream, n, L, l, hmin, hmax, axes, nodes_out);
     e = hipGetLastError();
-    if (e != hipSuccess) return done(e);
-    e = hipStreamSynchronize(stream);
-    if (e == hipSuccess) e = hipMemcpy(info_out, d_info, sizeof(DeviceSphereTreeInfo), hipMemcpyDeviceToHost);
+    if (L != 0u) {
+        info_out->root = 0u;
+        info_out->depth = levels4;
+        info_out->n_nodes = static_cast<uint32_t>(sphere_tree_node_capacity(n));
+    }
     return done(e);
 }
 

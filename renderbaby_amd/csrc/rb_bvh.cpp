@@ -16,6 +16,7 @@
 #include <array>
 #include <functional>
 #include <future>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -141,17 +142,18 @@ bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_st
 }
 
 
-// ---------------------------------------------------------------- sphere BVH --
+// ---------------------------------------------------------------- sphere tree --
 // The reference scans every sphere on every segment (shader.wgsl:574-586), which is
 // intractable beyond a few thousand spheres (BASELINE config C4 has 10^6).  This builds
-// a binary tree over the spheres' tight boxes (median split on the longest axis of the
-// centroid bounds, <= 4 spheres per leaf).  A node stores BOTH children's boxes, so one
-// visit decides both; the traversal (rb_kernels.hip, intersect_spheres_bvh) inflates the
-// boxes per ray by a margin that covers the rounding error of the reference's own
+// a tree over the spheres' tight boxes: median splits on the longest axis of the centres'
+// bounds down to leaves of <= kSphLeaf spheres, two levels of splits per 4-wide node
+// (rb_internal.hpp SphereNode4).  The traversal (rb_device_shade.hpp sphere_node_step, rb_kernels.hip
+// k_trace_sph) grows the boxes per ray by a margin that covers the rounding error of the reference's own
 // discriminant, runs the reference's exact intersect_sphere on every candidate and
-// breaks ties by the lower original index -- the winner of the linear scan.
+// breaks ties by the lower original index -- the winner of the linear scan.  The host builder is the fallback and the
+// checker of the device builder (rb_build.hip), which is the default from 1024 spheres up.
 namespace {
-// Both two-box builders fork big subtrees onto threads: the halves touch disjoint ranges of the
+// The library's two-box triangle builder forks big subtrees onto threads: the halves touch disjoint ranges of the
 // item array, the left one is built into its own node array, and appending left then right with
 // their node indices shifted reproduces the sequential (pre-order) numbering exactly.
 constexpr size_t kParallelCount = 16384;
@@ -168,9 +170,8 @@ inline void append_subtree(std::vector<SphereNode>& nodes, const std::vector<Sph
 struct SBuilder {
     const rb_sphere* sph;
     std::vector<uint32_t>& order;
-    std::vector<SphereNode>& nodes;
-    uint32_t max_depth = 0;
-    uint32_t par_levels = 0;   // levels below this call that may still fork a thread
+    std::vector<SphereNode4>& nodes;
+    uint32_t levels = 0;   // 4-wide levels on the deepest path
 
     void bounds(size_t first, size_t count, float mn[3], float mx[3]) const {
         for (int a = 0; a < 3; ++a) {
@@ -185,10 +186,8 @@ struct SBuilder {
             }
         }
     }
-    // returns a child reference: leaf = 0x80000000 | (count-1) << 27 | first ; node = index
-    uint32_t build(size_t first, size_t count, uint32_t depth) {
-        max_depth = std::max(max_depth, depth);
-        if (count <= kSphLeaf) return 0x80000000u | (static_cast<uint32_t>(count - 1) << 27) | static_cast<uint32_t>(first);
+    // median split of [first, first + count) along the longest axis of the centres; returns the axis
+    uint32_t split(size_t first, size_t count, size_t& mid) {
         float cmn[3], cmx[3];
         for (int a = 0; a < 3; ++a) {
             cmn[a] = std::numeric_limits<float>::infinity();
@@ -201,46 +200,57 @@ struct SBuilder {
             }
         const float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
         const int axis = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);
-        const size_t mid = first + count / 2;
+        mid = first + count / 2;
         std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                          [&](uint32_t a, uint32_t b) { return sph[a].center[axis] < sph[b].center[axis]; });
+        return static_cast<uint32_t>(axis);
+    }
+    static uint32_t leaf_ref(size_t first, size_t count) {
+        return 0x80000000u | (static_cast<uint32_t>(count - 1) << 27) | static_cast<uint32_t>(first);
+    }
+    void set_child(SphereNode4& n, int k, size_t first, size_t count, uint32_t ref) const {
+        float mn[3], mx[3];
+        bounds(first, count, mn, mx);
+        n.lox[k] = mn[0]; n.loy[k] = mn[1]; n.loz[k] = mn[2];
+        n.hix[k] = mx[0]; n.hiy[k] = mx[1]; n.hiz[k] = mx[2];
+        n.ref[k] = ref;
+    }
+    // returns a child reference: a leaf (count <= kSphLeaf) or the index of a node over two levels of splits
+    uint32_t build(size_t first, size_t count, uint32_t level) {
+        if (count <= kSphLeaf) return leaf_ref(first, count);
+        levels = std::max(levels, level);
         const uint32_t me = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
-        SphereNode n;
-        bounds(first, mid - first, n.lmin, n.lmax);
-        bounds(mid, first + count - mid, n.rmin, n.rmax);
-        if (count >= kParallelCount && par_levels > 0u) {
-            std::vector<SphereNode> lv, rv;
-            SBuilder lb{sph, order, lv, 0, par_levels - 1u}, rb{sph, order, rv, 0, par_levels - 1u};
-            auto fut = std::async(std::launch::async, [&] { return lb.build(first, mid - first, depth + 1); });
-            uint32_t rref = rb.build(mid, first + count - mid, depth + 1);
-            uint32_t lref = fut.get();
-            append_subtree(nodes, lv, lref);
-            append_subtree(nodes, rv, rref);
-            n.left = lref;
-            n.right = rref;
-            max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
-        } else {
-            n.left = build(first, mid - first, depth + 1);
-            n.right = build(mid, first + count - mid, depth + 1);
+        SphereNode4 n{};
+        for (int k = 0; k < 4; ++k) n.ref[k] = kSphNone;
+        size_t mid = 0;
+        n.axes = split(first, count, mid);
+        const size_t hf[2] = {first, mid}, hc[2] = {mid - first, first + count - mid};
+        for (int h = 0; h < 2; ++h) {
+            if (hc[h] <= kSphLeaf) {   // this half is a leaf already: one child
+                set_child(n, 2 * h, hf[h], hc[h], leaf_ref(hf[h], hc[h]));
+                continue;
+            }
+            size_t m2 = 0;
+            n.axes |= split(hf[h], hc[h], m2) << (2 + 2 * h);
+            const uint32_t r0 = build(hf[h], m2 - hf[h], level + 1), r1 = build(m2, hf[h] + hc[h] - m2, level + 1);
+            set_child(n, 2 * h, hf[h], m2 - hf[h], r0);
+            set_child(n, 2 * h + 1, m2, hf[h] + hc[h] - m2, r1);
         }
-        n._pad0 = n._pad1 = 0;
         nodes[me] = n;
         return me;
     }
 };
 }  // namespace
 
-void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode>& nodes,
-                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
-                      float bmax[3]) {
+void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode4>& nodes,
+                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth) {
     nodes.clear();
     order.resize(n);
     for (size_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
-    SBuilder b{spheres, order, nodes, 0, 6u};
-    b.bounds(0, n, bmin, bmax);
+    SBuilder b{spheres, order, nodes};
     *root_ref = n ? b.build(0, n, 1) : 0x80000000u;
-    *depth = b.max_depth + 1;
+    *depth = b.levels;
 }
 
 
@@ -877,15 +887,23 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         }
     }
     if (rank == 0 || rank >= (1u << 26) - 64u || order.size() > node_count) return false;
-    // ---- bottom-up: children before parents
     std::vector<ChunkInfo> info(node_count);
-    std::vector<ChunkItem> items;
-    ChunkBuilder cb{out, items};
-    for (size_t k = order.size(); k-- > 0;) {
-        const uint32_t ni = order[k];
-        const rb_bvh_node& n = ref_nodes[ni];
-        ChunkInfo& r = info[ni];
-        if (n.primitive_count > 0) {
+    // ---- the library's own levels below every reference leaf.  The leaves are independent, so they are built in parallel
+    // (C5's 8 192 leaves of 128 triangles: 85 ms on one thread), each into arrays of its own with references that count from
+    // zero; laid end to end afterwards, the references shifted by where a leaf's arrays landed.
+    std::vector<uint32_t> leaves;
+    for (uint32_t ni : order)
+        if (ref_nodes[ni].primitive_count > 0) leaves.push_back(ni);
+    struct LeafOut {
+        ChunkTree t;
+        ChunkInfo info;
+    };
+    std::vector<LeafOut> lout(leaves.size());
+    auto build_range = [&](size_t first, size_t last) {
+        std::vector<ChunkItem> items;
+        for (size_t li = first; li < last; ++li) {
+            const uint32_t ni = leaves[li];
+            const rb_bvh_node& n = ref_nodes[ni];
             items.clear();
             uint32_t rk = leaf_rank0[ni];
             for (uint32_t i = 0; i < n.primitive_count; ++i) {
@@ -912,8 +930,62 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                 for (int a = 0; a < 3; ++a) it.n[a] = b.n[a];
                 items.push_back(it);
             }
-            if (!items.empty()) r = cb.build_leaf(0, items.size());
+            if (items.empty()) continue;
+            ChunkBuilder cb{lout[li].t, items};
+            lout[li].info = cb.build_leaf(0, items.size());
+        }
+    };
+    {
+        const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
+        size_t threads = (seq && seq[0] == '1') ? 1u : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        if (rank < 16384u) threads = 1;
+        threads = std::min(threads, leaves.size());
+        if (threads <= 1) {
+            build_range(0, leaves.size());
         } else {
+            std::vector<std::thread> pool;
+            const size_t per = (leaves.size() + threads - 1) / threads;
+            for (size_t t = 0; t < threads; ++t)
+                pool.emplace_back(build_range, std::min(t * per, leaves.size()), std::min((t + 1) * per, leaves.size()));
+            for (std::thread& th : pool) th.join();
+        }
+    }
+    {
+        size_t n_nodes = 0, n_pos = 0;
+        for (const LeafOut& l : lout) {
+            n_nodes += l.t.nodes.size();
+            n_pos += l.t.pos_slot.size();
+        }
+        if (n_pos >= (1u << 26) || n_nodes >= (1u << 30)) return false;
+        out.nodes.reserve(n_nodes + order.size());
+        out.pos_slot.reserve(n_pos);
+        out.pos_rank.reserve(n_pos);
+        for (size_t li = 0; li < lout.size(); ++li) {
+            LeafOut& l = lout[li];
+            const uint32_t node_off = static_cast<uint32_t>(out.nodes.size()), pos_off = static_cast<uint32_t>(out.pos_slot.size());
+            auto moved = [&](uint32_t ref) {   // leaf: first position += pos_off; node: index += node_off
+                if (ref == kChunkNone) return ref;
+                return (ref & kChunkLeaf) ? ref + pos_off : ref + node_off;
+            };
+            for (ChunkNode c : l.t.nodes) {
+                c.lref = moved(c.lref);
+                c.rref = moved(c.rref);
+                out.nodes.push_back(c);
+            }
+            out.pos_slot.insert(out.pos_slot.end(), l.t.pos_slot.begin(), l.t.pos_slot.end());
+            out.pos_rank.insert(out.pos_rank.end(), l.t.pos_rank.begin(), l.t.pos_rank.end());
+            l.info.ref = moved(l.info.ref);
+            info[leaves[li]] = l.info;
+            l.t = ChunkTree{};
+        }
+    }
+    // ---- bottom-up over the caller's internal nodes: children before parents
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t ni = order[k];
+        const rb_bvh_node& n = ref_nodes[ni];
+        ChunkInfo& r = info[ni];
+        if (n.primitive_count > 0) continue;
+        {
             const bool hl = n.left < node_count, hr = n.right < node_count;
             const ChunkInfo none;
             const ChunkInfo& l = hl ? info[n.left] : none;
@@ -921,6 +993,9 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             if (l.ref == kChunkNone && rr.ref == kChunkNone) continue;   // nothing to hit below
             ChunkNode c{};
             const float zero[3] = {0, 0, 0};
+            std::vector<ChunkItem> no_items;
+            ChunkTree no_tree;
+            ChunkBuilder cb{no_tree, no_items};
             cb.fill_child(l, hl ? ref_nodes[n.left].aabb_min : zero, hl ? ref_nodes[n.left].aabb_max : zero, c.lmin, c.lref, c.lmax,
                           c.lfac, c.lcone);
             cb.fill_child(rr, hr ? ref_nodes[n.right].aabb_min : zero, hr ? ref_nodes[n.right].aabb_max : zero, c.rmin, c.rref,

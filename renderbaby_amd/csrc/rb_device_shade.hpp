@@ -68,7 +68,7 @@ DEV bool near_zero(f3 v) {                                                // :46
 //    `t < best || (t == best && id < best_id)`;
 //  * a subtree is skipped only if no sphere below it can be REPORTED hit nearer than the best t so far.  The reference's
 //    discriminant hb^2 - a (|oc|^2 - r^2) carries an absolute error <= E u a D^2 (u = 2^-24; D >= max(|oc|, r); E < 24:
-//    tools/sphere_margin_check.py measures 7.1 at most, first-order bound 20), so
+//    tools/sphere_margin_check.py measures 8.9 at most over 43 M reported hits, a first-order count gives 20), so
 //      across the ray: a sphere is reported hit only by a ray whose LINE passes within r + sqrt(E u) D of its centre:
 //        the line's point nearest the centre (parameter t_c) lies in the sphere's box grown by mm = kSphK D;
 //      along the ray: the reported t^ = t_c -+ sqrt(disc^) / a is within dt = kSphK D / |d| of a point of the chord
@@ -76,15 +76,12 @@ DEV bool near_zero(f3 v) {                                                // :46
 //    So with [tn, tf] = where the line is inside the child's box grown by mm, every reported t^ of a sphere below lies
 //    in [tn - dt, tf + dt]; it must be positive and, to win, below the best t.  D = distance from the origin to the box's
 //    farthest corner >= max(|oc|, r) for every sphere inside the box.  kSphK = 1.25e-3 = sqrt(26 u): both parts of
-//    r03's single 3e-3 D box inflation, each now where it belongs (a third of the cross-section on far boxes).
+//    r03's single 3e-3 D box inflation, each now where it belongs.
 constexpr float kSphK = 1.25e-3f * 1.001f;   // * 1.001: v_sqrt_f32 / v_rsq_f32 are within 1 ulp, the slab arithmetic a few more
 constexpr float kSphAbs = 1e-4f;             // absolute part: the boxes' own rounding (c -+ r in f32), tiny scenes
-struct SphereCull {
-    float mm, dt;
-};
-// one child box: enter?  `tn` = where the line enters the grown box (nearer child first).  NaN anywhere means "enter".
-DEV bool sphere_child(v4f lo, v4f hi, f3 o, f3 inv, float rs, float best, float& tn) {
-    const f3 a = mk(lo.x, lo.y, lo.z) - o, b = mk(hi.x, hi.y, hi.z) - o;
+// one child box: enter?  `tn` = where the line enters the grown box.  NaN anywhere means "enter".
+DEV bool sphere_child(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float rs, float best, float& tn) {
+    const f3 a = mk(lox, loy, loz) - o, b = mk(hix, hiy, hiz) - o;
     float mx, my, mz;
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(a.x), "v"(b.x));
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(my) : "v"(a.y), "v"(b.y));
@@ -104,91 +101,86 @@ DEV bool sphere_child(v4f lo, v4f hi, f3 o, f3 inv, float rs, float best, float&
 // 16-byte {centre, radius} records (sph_leaf) with their original indices beside them (sph_id).
 DEV uint32_t sph_leaf_first(uint32_t ref) { return ref & 0x07FFFFFFu; }
 DEV uint32_t sph_leaf_count(uint32_t ref) { return ((ref >> 27) & 15u) + 1u; }
+// which components of the direction are negative: a node's children are visited in the order of these signs
+DEV uint32_t sph_dir_signs(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
 
-// The per-lane form: resumable (like FastWalk); the per-segment kernels and segment_finish run it to completion,
-// k_trace_sph has its own pooled walk (rb_kernels.hip).
-struct SphereWalk {
-    f3 o, d, inv;
-    float a, rs, best;
-    uint32_t best_id, cur;
-    int sp;
+// One 4-wide node (rb_internal.hpp SphereNode4): the up to four child boxes against the ray; returns the entered child the
+// ray meets first (kSphNone: none) and hands the other entered ones to `push`, farthest first -- "first" by the split
+// planes: the half on the ray's side of the top split before the other, and inside a half the child on its side of that
+// half's split (any order is correct: the walk culls on the best t; this one costs a few selects instead of a sort).
+template <class Push>
+DEV uint32_t sphere_node_step(const KParams& p, uint32_t node, f3 o, f3 inv, uint32_t dneg, float rs, float best, Push&& push) {
+    const cf4p q = (cf4p)p.sph_nodes + (size_t)node * 8u;
+    const v4f lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5];
+    const v4u rf = ((cu4p)p.sph_nodes)[(size_t)node * 8u + 6u], mt = ((cu4p)p.sph_nodes)[(size_t)node * 8u + 7u];
+    float t0, t1, t2, t3;
+    bool e0 = sphere_child(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, rs, best, t0) && rf.x != kSphNone;
+    bool e1 = sphere_child(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, rs, best, t1) && rf.y != kSphNone;
+    bool e2 = sphere_child(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, rs, best, t2) && rf.z != kSphNone;
+    bool e3 = sphere_child(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, rs, best, t3) && rf.w != kSphNone;
+    uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+    const uint32_t ax = mt.x;
+    const bool f0 = ((dneg >> (ax & 3u)) & 1u) != 0u, f1 = ((dneg >> ((ax >> 2) & 3u)) & 1u) != 0u, f2 = ((dneg >> ((ax >> 4) & 3u)) & 1u) != 0u;
+    auto swap_if = [](bool c, uint32_t& ra, bool& ea, uint32_t& rb, bool& eb) {
+        const uint32_t r = c ? rb : ra;
+        rb = c ? ra : rb;
+        ra = r;
+        const bool e = c ? eb : ea;
+        eb = c ? ea : eb;
+        ea = e;
+    };
+    swap_if(f1, r0, e0, r1, e1);   // a ray going down the lower half's axis meets child 1 first
+    swap_if(f2, r2, e2, r3, e3);
+    swap_if(f0, r0, e0, r2, e2);   // ... and one going down the top split's axis the upper half
+    swap_if(f0, r1, e1, r3, e3);
+    if (e3 && (e0 || e1 || e2)) push(r3);
+    if (e2 && (e0 || e1)) push(r2);
+    if (e1 && e0) push(r1);
+    return e0 ? r0 : e1 ? r1 : e2 ? r2 : e3 ? r3 : kSphNone;
+}
 
-    DEV void begin(const KParams& p, f3 o_, f3 d_, float a_, float closest_t) {
-        o = o_;
-        d = d_;
-        a = a_;
-        rs = 1.001f * __builtin_amdgcn_rsqf(a_);   // 1 / |d|
-        inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
-        best = closest_t;
-        best_id = 0xFFFFFFFFu;
-        cur = p.sph_root;
-        sp = 0;
-    }
-    DEV bool at_leaf() const { return (cur & 0x80000000u) != 0u; }
-    DEV bool pop(const uint32_t* stack, uint32_t stride) {
-        if (sp == 0) return false;
-        sp--;
-        cur = stack[sp * stride];
-        return true;
-    }
-    // false when the walk is complete
-    DEV bool node_step(const KParams& p, uint32_t* stack, uint32_t stride) {
-        const cf4p nodes = (cf4p)p.sph_nodes;
-        const v4f l0 = nodes[cur * 4u], l1 = nodes[cur * 4u + 1u], r0 = nodes[cur * 4u + 2u], r1 = nodes[cur * 4u + 3u];
-        const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
-        float tl_, tr_;
-        const bool hl = sphere_child(l0, l1, o, inv, rs, best, tl_), hr = sphere_child(r0, r1, o, inv, rs, best, tr_);
-        if (hl && hr) {
-            // nearer child first; the other waits on the stack
-            const bool left_first = !(tr_ < tl_);
-            stack[sp * stride] = left_first ? rref : lref;
-            sp++;
-            cur = left_first ? lref : rref;
-            return true;
-        }
-        if (hl) {
-            cur = lref;
-            return true;
-        }
-        if (hr) {
-            cur = rref;
-            return true;
-        }
-        return pop(stack, stride);
-    }
-    DEV bool leaf_step(const KParams& p, uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
-        const cf4p leafs = (cf4p)p.sph_leaf;
-        const RB_CONST uint32_t* ids = cptr(p.sph_id);
-        const uint32_t first = sph_leaf_first(cur), count = sph_leaf_count(cur);
-        for (uint32_t j = first; j < first + count; j++) {
-            const v4f cr = leafs[j];
-            const uint32_t id = ids[j];
-            if (n_tested) (*n_tested)++;
-            const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
-            // strictly nearer than everything so far; equal t only displaces a SPHERE of higher index (the scan's order):
-            // a tie with the ground / triangle hit the walk started from loses, as in the reference (best_id still unset)
-            if (t > 0.001f && (t < best || (t == best && best_id != 0xFFFFFFFFu && id < best_id))) {
-                best = t;
-                best_id = id;
-            }
-        }
-        return pop(stack, stride);
-    }
-    DEV void result(float& closest_t, uint32_t& sphere_idx) const {
-        if (best_id != 0xFFFFFFFFu) {
-            closest_t = best;
-            sphere_idx = best_id;
-        }
-    }
-};
-
+// The per-lane walk, run to completion: the per-segment kernels and segment_finish of the mesh walks (k_trace_sph has
+// its own pooled form of the leaves, rb_kernels.hip).
 DEV void intersect_spheres_bvh(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx,
                                uint32_t* stack, uint32_t stride, unsigned long long* n_tested) {
-    SphereWalk w;
-    w.begin(p, o, d, a, closest_t);
-    bool more = true;
-    while (more) more = w.at_leaf() ? w.leaf_step(p, stack, stride, n_tested) : w.node_step(p, stack, stride);
-    w.result(closest_t, sphere_idx);
+    const f3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // steers only (1 ulp: within the margin)
+    const float rs = 1.001f * __builtin_amdgcn_rsqf(a);   // 1 / |d|
+    const uint32_t dneg = sph_dir_signs(d);
+    const cf4p leafs = (cf4p)p.sph_leaf;
+    const RB_CONST uint32_t* ids = cptr(p.sph_id);
+    float best = closest_t;
+    uint32_t best_id = 0xFFFFFFFFu, cur = p.sph_root;
+    int sp = 0;
+    for (;;) {
+        if (cur != kSphNone && (cur & 0x80000000u) == 0u) {
+            cur = sphere_node_step(p, cur, o, inv, dneg, rs, best, [&](uint32_t ref) {
+                stack[sp * stride] = ref;
+                sp++;
+            });
+            if (cur != kSphNone) continue;
+        } else if (cur != kSphNone) {
+            const uint32_t first = sph_leaf_first(cur), count = sph_leaf_count(cur);
+            for (uint32_t j = first; j < first + count; j++) {
+                const v4f cr = leafs[j];
+                const uint32_t id = ids[j];
+                if (n_tested) (*n_tested)++;
+                const float t = isect_sphere(o, d, a, mk(cr.x, cr.y, cr.z), cr.w);
+                // strictly nearer than everything so far; equal t only displaces a SPHERE of higher index (the scan's order):
+                // a tie with the ground / triangle hit the walk started from loses, as in the reference (best_id still unset)
+                if (t > 0.001f && (t < best || (t == best && best_id != 0xFFFFFFFFu && id < best_id))) {
+                    best = t;
+                    best_id = id;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * stride];
+    }
+    if (best_id != 0xFFFFFFFFu) {
+        closest_t = best;
+        sphere_idx = best_id;
+    }
 }
 
 // One iteration of the bounce loop, shader.wgsl:534-660.  Returns true when the

@@ -20,7 +20,7 @@ constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (L
 // kernels assert the entry size where they take their column (StackColumn), the runtime the depth where it sets
 // stack_depth (stack_depth_covers).
 constexpr uint32_t kStackEntryBytes = 4;
-constexpr uint32_t kDefaultStripeRows = 16;
+constexpr uint32_t kDefaultStripeRows = 8;   // = the kernel tile's 8 rows: a tile's rays stay neighbours, the shards stay balanced (profiles/r04_shard_rehearsal.txt)
 
 // ---- rb_bvh.cpp
 void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_node>& nodes,
@@ -28,16 +28,10 @@ void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_no
 bool bvh_validate(const rb_bvh_node* nodes, uint32_t node_count, uint32_t max_stack, std::string& why,
                   uint32_t* depth_out);
 
-// Sphere acceleration structure (no reference counterpart; see rb_bvh.cpp).  64 B per node.  (The library's own triangle
-// tree of DESIGN.md section 4.1 uses the same node with leaves of <= 2: 0x80000000 | (count-1) << 28 | first.)
-#ifndef RB_SPH_LEAF
-#define RB_SPH_LEAF 16
-#endif
-constexpr uint32_t kSphLeaf = RB_SPH_LEAF;   // spheres per leaf = lanes per (ray, leaf) pair of k_trace_sph: 8 or 16
-static_assert(kSphLeaf == 8 || kSphLeaf == 16, "a sphere leaf is tested by 8 or 16 lanes");
+// The two-box node of the library's own TRIANGLE tree (leaves of <= 2: 0x80000000 | (count-1) << 28 | first).
 struct alignas(16) SphereNode {
     float lmin[3];
-    uint32_t left;    // child reference: node index, or sphere leaf = 0x80000000 | (count-1) << 27 | first (count <= kSphLeaf)
+    uint32_t left;    // child reference: node index, or leaf = 0x80000000 | (count-1) << 28 | first
     float lmax[3];
     uint32_t right;
     float rmin[3];
@@ -46,19 +40,43 @@ struct alignas(16) SphereNode {
     uint32_t _pad1;
 };
 static_assert(sizeof(SphereNode) == 64, "SphereNode is 64 B");
+// ---- Sphere acceleration structure (no reference counterpart: shader.wgsl:574-586 scans; BASELINE C4 has 10^6 spheres).
+// A 4-wide tree: every node holds the boxes of up to four children (two levels of median splits collapsed into one), so a
+// ray's walk makes half as many DEPENDENT node fetches as with two-box nodes -- the walk waits on them (r04: 48 % of wave
+// cycles with two-box nodes).  128 B, component-major, so the four box tests read like one.  Leaves are runs of at most
+// kSphLeaf spheres of the leaf order: consecutive 16-byte {centre, radius} records (sph_leaf) with their original indices
+// beside them (sph_id), tested one sphere per lane by k_trace_sph.
+#ifndef RB_SPH_LEAF
+#define RB_SPH_LEAF 16
+#endif
+constexpr uint32_t kSphLeaf = RB_SPH_LEAF;   // spheres per leaf = lanes per (ray, leaf) pair of k_trace_sph: 8 or 16
+static_assert(kSphLeaf == 8 || kSphLeaf == 16, "a sphere leaf is tested by 8 or 16 lanes");
+constexpr uint32_t kSphNone = 0xFFFFFFFFu;
+struct alignas(16) SphereNode4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];   // child k's box: (lox[k], loy[k], loz[k]) .. (hix[k], hiy[k], hiz[k])
+    uint32_t ref[4];   // child reference: kSphNone | node index | leaf = 0x80000000 | (count-1) << 27 | first (count <= kSphLeaf)
+    uint32_t axes;     // children 0,1 = the lower half of the split along axis (axes & 3), cut along (axes >> 2) & 3; children 2,3 = the
+    uint32_t _pad[3];  // upper half, cut along (axes >> 4) & 3: a ray visits the halves, and the children of a half, in the order of its direction's signs
+};
+static_assert(sizeof(SphereNode4) == 128, "SphereNode4 is 128 B");
 constexpr uint32_t kSphereBvhThreshold = 64;  // use the linear two-pass scan up to this many spheres
 constexpr uint32_t kSphereDeviceBuildMin = 1024;  // from here up the sphere tree is built on the device by default
-void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode>& nodes,
-                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth, float bmin[3],
-                      float bmax[3]);
-// The same structure made on the device (rb_build.hip): Morton order of the centres, leaves of kSphLeaf consecutive
-// spheres, an LBVH over the leaves.  `spheres` is the device copy; nodes_out holds ceil(n / kSphLeaf) - 1 nodes,
-// leaf_out n float4 {centre, radius}, id_out n original indices.  Synchronises `stream`.
+// host builder (rb_bvh.cpp): median splits on the longest axis of the centres.  depth = 4-wide levels.
+void sphere_bvh_build(const rb_sphere* spheres, size_t n, std::vector<SphereNode4>& nodes,
+                      std::vector<uint32_t>& order, uint32_t* root_ref, uint32_t* depth);
+// The same tree made on the device (rb_build.hip): level by level, every level one segmented sort of the centres along each
+// segment's longest axis -- the median splits of the host builder, a complete tree.  `spheres` is the device copy; nodes_out
+// holds sphere_tree_node_capacity(n) nodes, leaf_out n float4 {centre, radius}, id_out n original indices.  Synchronises `stream`.
 struct DeviceSphereTreeInfo {
-    uint32_t root, depth;
+    uint32_t root, depth, n_nodes;
 };
-int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode* nodes_out, float* leaf_out, uint32_t* id_out,
+size_t sphere_tree_node_capacity(size_t n);
+int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode4* nodes_out, float* leaf_out, uint32_t* id_out,
                             DeviceSphereTreeInfo* info_out, void* stream);
+// a node leaves at most three children waiting, so 3 entries per level is all a walk can hold at once (not one more: for
+// C4's eight levels the 24-entry columns plus k_trace_sph's 15 KiB of wave corners are 39.4 KiB per block, four blocks per
+// CU; a 25th entry would make it three)
+inline uint32_t sphere_stack_entries(uint32_t levels4) { return 3u * levels4; }
 
 // Walk of multi-node meshes when the caller's flags do not say: the chunked walk (ChunkTree below),
 // at every size.  Should its tree not be buildable (a tree deeper than the LDS stack, a leaf root), the library's own
@@ -253,7 +271,7 @@ struct KParams {
     const uint32_t* chunk_rank_slot; // rank -> slot
     uint32_t chunk_root;           // root child reference (the root's own box is nodes[0]'s)
     uint32_t chunk_n;              // positions
-    const SphereNode* sph_nodes;   // sphere BVH (nullptr => linear scan)
+    const SphereNode4* sph_nodes;  // sphere tree (nullptr => linear scan)
     const float* sph_leaf;         // float4 {centre, radius} in leaf order
     const uint32_t* sph_id;        // original sphere index per leaf-order slot
     uint32_t sph_root;             // root child reference

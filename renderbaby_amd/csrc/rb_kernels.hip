@@ -1090,8 +1090,9 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 // sphere on every segment (shader.wgsl:574-586); the library walks its own tree (rb_internal.hpp SphereNode; built on the
 // device, rb_build.hip) between segment_pre (ground, the at most single-node triangle list) and segment_post (lights,
 // shading), with the two shapes of work of k_trace_chunk:
-//   lane = RAY for the tree: every lane walks its own ray down the two-box nodes, nearer child first, a child skipped only
-//     when no sphere below it can be REPORTED hit nearer than the best t (sphere_child, rb_device_shade.hpp);
+//   lane = RAY for the tree: every lane walks its own ray down the 4-wide nodes (half as many dependent fetches as with
+//     two-box nodes: the walk waits on them), a child skipped only when no sphere below it can be REPORTED hit nearer than
+//     the best t (sphere_child / sphere_node_step, rb_device_shade.hpp);
 //   lane = SPHERE for the leaves: the (ray, leaf) pairs of all 64 lanes are pooled, every round 64 / kSphLeaf of them are
 //     tested by kSphLeaf lanes each -- one sphere per lane, the leaf's 16-byte {centre, radius} records read as consecutive
 //     bytes, the ray from LDS -- in two steps: the reference's discriminant for every lane (same operations, same bits:
@@ -1103,20 +1104,25 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 // r03's form (every lane its own node and its own <= 4-sphere leaf: 8 L1 accesses per sphere test, 46 % of the lanes busy,
 // 42 % of the wave cycles waiting) made 4.48 G segments/s on C4.
 #ifndef RB_SPH_WAVES
-#define RB_SPH_WAVES 5
+#define RB_SPH_WAVES 4   // 128 registers: nothing spilled; the LDS (stack columns of 3 entries per level + 3.75 KiB per wave) holds four blocks per CU anyway
 #endif
 #ifndef RB_SPH_NODE_LANES
-#define RB_SPH_NODE_LANES 32
+#define RB_SPH_NODE_LANES 24
 #endif
 #ifndef RB_SPH_NODE_STEPS
-#define RB_SPH_NODE_STEPS 5
+#define RB_SPH_NODE_STEPS 8
 #endif
 #ifndef RB_SPH_LEAF_LANES
 #define RB_SPH_LEAF_LANES 8
 #endif
 #ifndef RB_SPH_FINISH_LANES
-#define RB_SPH_FINISH_LANES 32
+#define RB_SPH_FINISH_LANES 48
 #endif
+#ifndef RB_SPH_PER_LANE
+#define RB_SPH_PER_LANE 2   // spheres a lane tests per round: a leaf's kSphLeaf spheres go to kSphLeaf / 2 lanes, which fetch the ray once for two tests
+#endif
+constexpr uint32_t kSphPerLane = RB_SPH_PER_LANE;
+static_assert(kSphPerLane == 1 || kSphPerLane == 2, "one or two spheres per lane and round");
 #ifdef RB_SPH_PROFILE
 __device__ unsigned long long g_sph_prof[16];
 #define SPH_PROF(i, v) prof[i] += (v)
@@ -1124,7 +1130,6 @@ __device__ unsigned long long g_sph_prof[16];
 #define SPH_PROF(i, v)
 #endif
 constexpr uint32_t kSphWaveLds = 64u * 32u + 64u * 8u + 64u * 4u + 128u * 4u + 128u * 4u;   // per wave: ray records, best keys, a = d.d, units, survivors
-constexpr uint32_t kSphNone = 0xFFFFFFFFu;
 
 template <bool STATS>
 __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const KParams p) {
@@ -1167,6 +1172,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
     st.use_tex = st.tri_won_a = false;
     f3 inv = mk(0, 0, 0);
     float aa = 1.0f, rs = 1.0f;
+    uint32_t dneg = 0u;
     unsigned long long key = 0ull;
     int sp = 0;
     // a lane whose walk arrives at a leaf while it holds none aside keeps the leaf for the next leaf phase and goes on with
@@ -1215,6 +1221,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             inv = mk(__builtin_amdgcn_rcpf(pt.d.x), __builtin_amdgcn_rcpf(pt.d.y), __builtin_amdgcn_rcpf(pt.d.z));
             aa = dot(pt.d, pt.d);
             rs = 1.001f * __builtin_amdgcn_rsqf(aa);
+            dneg = sph_dir_signs(pt.d);
             key = (unsigned long long)__float_as_uint(st.closest_t) << 32;
             cur = fp.sph_root;
             pend = kSphNone;
@@ -1231,19 +1238,12 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             if (n == 0u || (it > 0 && n < (uint32_t)RB_SPH_NODE_LANES)) break;
             SPH_PROF(3, 1); SPH_PROF(4, n);
             if (at_node) {
-                const cf4p q = (cf4p)p.sph_nodes + (size_t)cur * 4u;
-                const v4f l0 = q[0], l1 = q[1], r0 = q[2], r1 = q[3];
-                const uint32_t lref = __float_as_uint(l0.w), rref = __float_as_uint(l1.w);
-                const float best_t = __uint_as_float((uint32_t)(key >> 32));
-                float kl, kr;
-                const bool vl = sphere_child(l0, l1, pt.o, inv, rs, best_t, kl), vr = sphere_child(r0, r1, pt.o, inv, rs, best_t, kr);
-                if (vl && vr) {
-                    const bool left_first = !(kr < kl);
-                    stack[sp * kTraceBlock] = left_first ? rref : lref;
+                const uint32_t nxt = sphere_node_step(p, cur, pt.o, inv, dneg, rs, __uint_as_float((uint32_t)(key >> 32)), [&](uint32_t ref) {
+                    stack[sp * kTraceBlock] = ref;
                     sp++;
-                    cur = left_first ? lref : rref;
-                } else if (vl || vr) {
-                    cur = vl ? lref : rref;
+                });
+                if (nxt != kSphNone) {
+                    cur = nxt;
                 } else if (sp != 0) {
                     sp--;
                     cur = stack[sp * kTraceBlock];
@@ -1265,7 +1265,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && cur != kSphNone && !lf));
             if (n_units != 0u && (n_units >= (uint32_t)RB_SPH_LEAF_LANES || n_node == 0u)) {
                 const unsigned long long below = (1ull << lane) - 1ull;
-                SPH_PROF(5, 1); SPH_PROF(6, n_units); SPH_PROF(7, (n_units + 64u / kSphLeaf - 1u) / (64u / kSphLeaf));
+                SPH_PROF(5, 1); SPH_PROF(6, n_units); SPH_PROF(7, (n_units + 64u * kSphPerLane / kSphLeaf - 1u) / (64u * kSphPerLane / kSphLeaf));
                 if (lp) units[(uint32_t)__popcll(mp & below)] = lane;
                 if (lf) units[n_pend + (uint32_t)__popcll(m & below)] = lane | 64u;
                 if (lf || lp) {
@@ -1279,7 +1279,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
                 __builtin_amdgcn_wave_barrier();
                 const cf4p leafs = (cf4p)p.sph_leaf;
                 const RB_CONST uint32_t* ids = cptr(p.sph_id);
-                constexpr uint32_t kPairsPerRound = 64u / kSphLeaf;
+                constexpr uint32_t kLanesPerUnit = kSphLeaf / kSphPerLane, kUnitsPerRound = 64u / kLanesPerUnit;
                 // the survivors of the discriminant, 64 at a time (or what is left): the whole intersect_sphere
                 uint32_t n_cand = 0u;
                 auto flush = [&](uint32_t k) {
@@ -1300,43 +1300,54 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
                     }
                     n_cand -= k;
                 };
+                // one round = kUnitsPerRound pairs; a pair's leaf is tested by kLanesPerUnit lanes, kSphPerLane spheres each; the
+                // next round's ray records and sphere records are requested before this round's are tested
                 struct Round {
-                    v4f r0, r1, cr;
+                    v4f r0, r1, cr[kSphPerLane];
                     float a;
-                    uint32_t tag;   // pair << 4 | sphere
-                    bool valid;
+                    uint32_t tag;     // pair << 4 | first sphere of this lane
+                    uint32_t cnt;     // spheres in the leaf (0: no pair for this lane)
                 };
                 auto fetch = [&](uint32_t g0) {
                     Round r;
-                    const uint32_t g = g0 + lane / kSphLeaf;
+                    const uint32_t g = g0 + lane / kLanesPerUnit;
                     const bool ok = g < n_units;
                     const uint32_t e = units[ok ? g : 0u], rl = e & 63u;
                     r.r0 = rayrec[rl * 2u];
                     r.r1 = rayrec[rl * 2u + 1u];
                     r.a = ray_a[rl];
-                    const uint32_t ref = __float_as_uint((e & 64u) ? r.r1.w : r.r0.w), j = lane & (kSphLeaf - 1u);
-                    r.valid = ok && j < sph_leaf_count(ref);
-                    r.cr = leafs[sph_leaf_first(ref) + (r.valid ? j : 0u)];
+                    const uint32_t ref = __float_as_uint((e & 64u) ? r.r1.w : r.r0.w), j = lane & (kLanesPerUnit - 1u);
+                    r.cnt = ok ? sph_leaf_count(ref) : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < kSphPerLane; k++) {
+                        const uint32_t jj = j + k * kLanesPerUnit;
+                        r.cr[k] = leafs[sph_leaf_first(ref) + (jj < r.cnt ? jj : 0u)];
+                    }
                     r.tag = (g << 4) | j;
                     return r;
                 };
                 Round nx = fetch(0u);
 #pragma unroll 1
-                for (uint32_t g0 = 0; g0 < n_units; g0 += kPairsPerRound) {
+                for (uint32_t g0 = 0; g0 < n_units; g0 += kUnitsPerRound) {
                     const Round r = nx;
-                    if (g0 + kPairsPerRound < n_units) nx = fetch(g0 + kPairsPerRound);
-                    if constexpr (STATS) tl.spheres += r.valid ? 1u : 0u;
-                    // shader.wgsl:194-199, the operations of isect_sphere up to its first return
-                    const f3 oc = mk(r.r0.x, r.r0.y, r.r0.z) - mk(r.cr.x, r.cr.y, r.cr.z), d = mk(r.r1.x, r.r1.y, r.r1.z);
-                    const float half_b = dot(oc, d);
-                    const float c = dot(oc, oc) - r.cr.w * r.cr.w;
-                    const float disc = half_b * half_b - r.a * c;
-                    const bool cand = r.valid && !(disc < 0.0f);
-                    const unsigned long long cm = __ballot(cand);
-                    if (cm != 0ull) {
-                        if (cand) cands[n_cand + (uint32_t)__popcll(cm & below)] = r.tag;
-                        n_cand += (uint32_t)__popcll(cm);
-                        if (n_cand >= 64u) flush(64u);
+                    if (g0 + kUnitsPerRound < n_units) nx = fetch(g0 + kUnitsPerRound);
+                    const f3 ro = mk(r.r0.x, r.r0.y, r.r0.z), d = mk(r.r1.x, r.r1.y, r.r1.z);
+#pragma unroll
+                    for (uint32_t k = 0; k < kSphPerLane; k++) {
+                        const bool valid = (r.tag & 15u) + k * kLanesPerUnit < r.cnt;
+                        if constexpr (STATS) tl.spheres += valid ? 1u : 0u;
+                        // shader.wgsl:194-199, the operations of isect_sphere up to its first return
+                        const f3 oc = ro - mk(r.cr[k].x, r.cr[k].y, r.cr[k].z);
+                        const float half_b = dot(oc, d);
+                        const float c = dot(oc, oc) - r.cr[k].w * r.cr[k].w;
+                        const float disc = half_b * half_b - r.a * c;
+                        const bool cand = valid && !(disc < 0.0f);
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm != 0ull) {
+                            if (cand) cands[n_cand + (uint32_t)__popcll(cm & below)] = r.tag + k * kLanesPerUnit;
+                            n_cand += (uint32_t)__popcll(cm);
+                            if (n_cand >= 64u) flush(64u);
+                        }
                     }
                 }
                 if (n_cand != 0u) flush(n_cand);

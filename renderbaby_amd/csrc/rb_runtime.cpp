@@ -139,13 +139,13 @@ struct rb_engine {
     float chunk_build_ms = 0.0f;
     std::vector<rb_gpu_triangle> host_tris;  // kept while the library's own tree may be (re)built
     std::vector<uint32_t> host_indices;
-    DevBuf<rb::SphereNode> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
+    DevBuf<rb::SphereNode4> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
     DevBuf<float> sph_leaf;
     DevBuf<uint32_t> sph_id;
     uint32_t sph_root = 0, sph_depth = 0;
     bool sph_bvh = false;
     bool stack_depth_covers = true;    // set with KParams::stack_depth: every walk in use fits its LDS column
-    const char* sph_builder = "";      // "device-lbvh" | "host-median" | "" (linear scan)
+    const char* sph_builder = "";      // "device-median" | "host-median" | "" (linear scan)
     float sph_build_ms = 0.0f;
     DevBuf<float> colors;            // RB_KERNEL_STREAM: float4 per (pixel, sample) of one launch chunk
     uint64_t color_budget = 0;       // bytes `colors` may take (0 = ask the device at the next dispatch)
@@ -351,8 +351,8 @@ int prep_materials(rb_engine* e, rb_material* first, size_t stride, size_t n) {
 
 // Spheres beyond kSphereBvhThreshold get the library's own acceleration structure; the
 // reference's linear scan (shader.wgsl:574-586) stays the rule for small counts.  From kSphereDeviceBuildMin spheres
-// up the tree is made on the device from the copy that is already there (rb_build.hip: Morton order + LBVH over
-// kSphLeaf-sphere leaves; 10^6 spheres in a few milliseconds where the host's median splits take 0.1 s);
+// up the tree is made on the device from the copy that is already there (rb_build.hip: the same median splits, one
+// segmented sort per level; 10^6 spheres in milliseconds where the host takes 0.1 s);
 // RB_FLAG_SPHERE_TREE_HOST / RB_FLAG_SPHERE_TREE_DEVICE force either builder.  The frame does not depend on which one ran.
 int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
     e->sph_bvh = false;
@@ -361,29 +361,27 @@ int build_sphere_bvh(rb_engine* e, const rb_sphere* s, size_t n) {
     const auto t_begin = std::chrono::steady_clock::now();
     const bool force_host = (e->opt.flags & RB_FLAG_SPHERE_TREE_HOST) != 0u, force_dev = (e->opt.flags & RB_FLAG_SPHERE_TREE_DEVICE) != 0u;
     if (!force_host && (force_dev || n >= rb::kSphereDeviceBuildMin)) {
-        const size_t n_leaf = (n + rb::kSphLeaf - 1) / rb::kSphLeaf;
-        HIP_TRY(e, e->sph_nodes.resize(std::max<size_t>(n_leaf - 1, 1)));
+        HIP_TRY(e, e->sph_nodes.resize(rb::sphere_tree_node_capacity(n)));
         HIP_TRY(e, e->sph_leaf.resize(n * 4));
         HIP_TRY(e, e->sph_id.resize(n));
         rb::DeviceSphereTreeInfo info{};
         const int rc = rb::device_sphere_bvh_build(e->spheres.ptr, static_cast<uint32_t>(n), e->sph_nodes.ptr, e->sph_leaf.ptr, e->sph_id.ptr,
                                                    &info, e->stream);
         if (rc) return fail(e, RB_ERR_DEVICE, "device sphere tree build failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
-        if (info.depth <= rb::kStackDepth) {
-            e->sph_root = info.root;
-            e->sph_depth = info.depth;
-            e->sph_bvh = true;
-            e->sph_builder = "device-lbvh";
-            e->sph_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            return RB_OK;
-        }
-        // (a Morton tree deeper than the LDS stack -- heavily clustered centres: the host's median splits are balanced)
+        if (rb::sphere_stack_entries(info.depth) > rb::kStackDepth) return RB_OK;   // beyond 16 M spheres: the scan (the host's tree is as deep)
+        e->sph_root = info.root;
+        e->sph_depth = rb::sphere_stack_entries(info.depth);
+        e->sph_bvh = true;
+        e->sph_builder = "device-median";
+        e->sph_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return RB_OK;
     }
-    std::vector<rb::SphereNode> nodes;
+    std::vector<rb::SphereNode4> nodes;
     std::vector<uint32_t> order;
-    float bmin[3], bmax[3];
-    rb::sphere_bvh_build(s, n, nodes, order, &e->sph_root, &e->sph_depth, bmin, bmax);
-    if (e->sph_depth > rb::kStackDepth) return RB_OK;  // degenerate input: keep the linear scan
+    uint32_t levels4 = 0;
+    rb::sphere_bvh_build(s, n, nodes, order, &e->sph_root, &levels4);
+    if (rb::sphere_stack_entries(levels4) > rb::kStackDepth) return RB_OK;
+    e->sph_depth = rb::sphere_stack_entries(levels4);
     std::vector<float> leaf(n * 4);
     for (size_t j = 0; j < n; ++j) {
         const rb_sphere& sp = s[order[j]];
@@ -834,26 +832,13 @@ uint64_t color_budget_bytes(rb_engine* e) {
     return e->color_budget;
 }
 
-// dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400: passes
-// [first_pass, first_pass + n_passes) on top of slot `src`, into slot `dst` (the same slot, or the other one
-// when the iterator runs a pass ahead).
-int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int dst) {
-    int rc = ensure_prepared(e);
-    if (rc) return rc;
-    if (n_passes == 0 || e->width == 0 || e->local_rows == 0) {
-        e->last_launches = 0;
-        return RB_OK;
-    }
-    if (e->timing_pending) {  // fold the previous group's events before they are recorded again
-        rc = accumulate_timing(e);
-        if (rc) return rc;
-    }
+// The stream kernels' colour buffer for a group of n_passes passes, and the passes per launch it allows: one float4 per
+// (pixel, sample) of a launch chunk.  Keeps the item count below 2^31 and, unless the caller fixed the chunk, the buffer
+// within the budget; if the device cannot give even that, halves.  Allocates (lazily: the first dispatch, or rb_reserve).
+int reserve_colors(rb_engine* e, uint32_t n_passes, uint32_t* chunk_out) {
     const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
-    const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
     uint32_t chunk = e->opt.passes_per_launch ? e->opt.passes_per_launch : n_passes;
-    if (kernel == RB_KERNEL_STREAM) {
-        // One float4 per (pixel, sample) of a launch chunk.  Keep the item count below 2^31 and, unless the
-        // caller fixed the chunk, the buffer within the budget; if the device cannot give even that, halve.
+    if (kernel == RB_KERNEL_STREAM && n_passes != 0 && e->width != 0 && e->local_rows != 0) {
         const uint64_t tiles = static_cast<uint64_t>((e->width + 7) / 8) * ((e->local_rows + 7) / 8);
         const uint64_t per_pass = tiles * 64ull * e->prh.samples_per_pass;  // items per pass
         const uint64_t budget_items = color_budget_bytes(e) / 16ull;
@@ -871,6 +856,29 @@ int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int 
             chunk = (chunk + 1) / 2;
         }
     }
+    *chunk_out = chunk;
+    return RB_OK;
+}
+
+// dispatch_compute_progressive without the host sync -- gpu_wrapper.rs:365-400: passes
+// [first_pass, first_pass + n_passes) on top of slot `src`, into slot `dst` (the same slot, or the other one
+// when the iterator runs a pass ahead).
+int dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes, int src, int dst) {
+    int rc = ensure_prepared(e);
+    if (rc) return rc;
+    if (n_passes == 0 || e->width == 0 || e->local_rows == 0) {
+        e->last_launches = 0;
+        return RB_OK;
+    }
+    if (e->timing_pending) {  // fold the previous group's events before they are recorded again
+        rc = accumulate_timing(e);
+        if (rc) return rc;
+    }
+    const uint32_t kernel = e->opt.kernel ? e->opt.kernel : RB_KERNEL_STREAM;
+    const bool stats = (e->opt.flags & RB_FLAG_STATS) != 0;
+    uint32_t chunk = 0;
+    rc = reserve_colors(e, n_passes, &chunk);
+    if (rc) return rc;
     HIP_TRY(e, hipEventRecord(e->ev_begin, e->stream));
     uint32_t launches = 0;
     e->ev_used = 0;
@@ -1469,6 +1477,25 @@ int rb_dispatch(rb_engine* e, uint32_t first_pass, uint32_t n_passes) {
     if (rc) return rc;
     e->spec_valid = false;
     return dispatch(e, first_pass, n_passes, e->cur, e->cur);
+}
+
+int rb_reserve(rb_engine* e, uint32_t n_passes) {
+    if (!e) return RB_ERR_NULL_ARGUMENT;
+    std::lock_guard<std::mutex> lock(e->mu);
+    auto one = [&](rb_engine* p) {
+        set_device(p);
+        int rc = require_ready(p);
+        if (!rc) rc = ensure_prepared(p);
+        uint32_t chunk = 0;
+        if (!rc) rc = reserve_colors(p, n_passes, &chunk);
+        if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(p, RB_ERR_DEVICE, "synchronise failed");
+        return rc;
+    };
+    if (is_group(e)) {
+        for (auto& p : e->parts) PART_TRY(e, p.get(), one(p.get()));
+        return RB_OK;
+    }
+    return one(e);
 }
 
 int rb_sync(rb_engine* e) {

@@ -16,7 +16,7 @@ import numpy as np
 
 from ._lib import load
 
-DEFAULT_STRIPE_ROWS = 16
+DEFAULT_STRIPE_ROWS = 8   # = rb_internal.hpp kDefaultStripeRows = bench.py --stripe-rows: profiles/r04_shard_rehearsal.txt
 
 
 def shard_layout(height, rank, world, stripe_rows=DEFAULT_STRIPE_ROWS):

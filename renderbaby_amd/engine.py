@@ -312,6 +312,10 @@ class Engine:
     def dispatch(self, first_pass, n_passes):
         self._check(self._lib.rb_dispatch(self._h, first_pass, n_passes))
 
+    def reserve(self, n_passes):
+        """rb_reserve: what a dispatch of n_passes passes would allocate lazily (no tracing)."""
+        self._check(self._lib.rb_reserve(self._h, n_passes))
+
     def sync(self):
         self._check(self._lib.rb_sync(self._h))
 
@@ -360,7 +364,7 @@ class Engine:
         return name, ms.value
 
     def sphere_tree_builder(self):
-        """("device-lbvh" | "host-median" | "", build milliseconds) of the library's sphere tree (> 64 spheres)."""
+        """("device-median" | "host-median" | "", build milliseconds) of the library's sphere tree (> 64 spheres)."""
         ms = C.c_float()
         name = (self._lib.rb_sphere_tree_builder(self._h, C.byref(ms)) or b"").decode()
         return name, ms.value

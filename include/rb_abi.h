@@ -443,10 +443,11 @@ int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_
  * dot on n input pairs (out8n: 8*n floats) so tests can check them against
  * IEEE-754 results computed on the host. */
 int rb_debug_math(const float* a, const float* b, float* out8n, uint32_t n);
-/* Measurement aid: pass-occupancy counters of k_trace_sph in a library built with -DRB_SPH_PROFILE (tools/sph_profile.py:
- * outer iterations, begin / node / leaf / finish passes and the lanes, pairs, rounds and survivors in them), summed over
- * every launch since the last reset.  The product build counts nothing and returns RB_ERR_DEVICE. */
-int rb_debug_walk_profile(uint64_t out16[16], int reset);
+/* Measurement aid: the pass / phase occupancy counters of a library built from sources with tools/ablate/rb_profile.patch
+ * applied (tools/walk_profile.sh: k_trace_sph's passes and the lanes, pairs, rounds and survivors in them; k_trace's lanes per
+ * phase of its loop body), summed over every launch since the last reset.  The product build carries no counting code and
+ * returns RB_ERR_DEVICE. */
+int rb_debug_walk_profile(uint64_t out64[64], int reset);
 /* Test hook: checks the kernels' fast exact reciprocal against the compiler's correctly rounded
  * 1/b for all 2^23 significands (both signs) at one biased exponent; out16[0] = mismatch count. */
 int rb_debug_rcp_exhaustive(uint32_t biased_exponent, uint32_t* out16);

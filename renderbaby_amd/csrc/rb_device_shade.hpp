@@ -245,16 +245,21 @@ DEV SegState segment_pre(const KParams& p, const Path& pt, const TriHit th, Tall
 // keeps the same winner.  Most lanes have no candidate, so the expensive tail is issued
 // once or twice per segment instead of once per sphere.
 // Spheres, shader.wgsl:574-586 -- per-segment form (the sphere tree run to completion, or the scan)
-template <bool STATS>
+// SPHTREE = false: an instantiation for launches without a sphere tree (at most 64 spheres): the tree's walk, with its 32
+// registers of node, stays out of the kernel's register allocation (k_trace for C2: 32 spilled registers with it, 4 without)
+template <bool STATS, bool SPHTREE = true>
 DEV void segment_spheres(const KParams& p, f3 o, f3 d, float a, float& closest_t, uint32_t& sphere_idx, uint32_t* stack,
                          uint32_t stride, Tally<STATS>& tl) {
     const uint32_t ns = p.u.spheres_count;
     const cf4p sph4 = (cf4p)p.spheres;  // 96 B = 6 x float4 per sphere; [0] = centre, radius
-    if (p.sph_nodes != nullptr) {
-        unsigned long long* cnt = nullptr;
-        if constexpr (STATS) cnt = &tl.spheres;
-        intersect_spheres_bvh(p, o, d, a, closest_t, sphere_idx, stack, stride, cnt);
-    } else
+    if constexpr (SPHTREE) {
+        if (p.sph_nodes != nullptr) {
+            unsigned long long* cnt = nullptr;
+            if constexpr (STATS) cnt = &tl.spheres;
+            intersect_spheres_bvh(p, o, d, a, closest_t, sphere_idx, stack, stride, cnt);
+            return;
+        }
+    }
     for (uint32_t base = 0; base < ns; base += 32u) {
         const uint32_t n = (ns - base < 32u) ? ns - base : 32u;
         uint32_t cand = 0u;
@@ -419,21 +424,22 @@ DEV bool segment_post(const KParams& p, Path& pt, const TriHit th, const SegStat
 }
 
 // One iteration of the bounce loop after the triangle traversal (`th`: its winner).
-template <bool STATS>
+template <bool STATS, bool SPHTREE = true>
 DEV bool segment_finish(const KParams& p, Path& pt, const TriHit th, uint32_t* stack, uint32_t stride,
                         Tally<STATS>& tl) {
     const SegState st = segment_pre<STATS>(fresh_params(p), pt, th, tl);
     float closest_t = st.closest_t;
     uint32_t sphere_idx = 0xFFFFFFFFu;
-    segment_spheres<STATS>(fresh_params(p), pt.o, pt.d, dot(pt.d, pt.d), closest_t, sphere_idx, stack, stride, tl);
+    segment_spheres<STATS, SPHTREE>(fresh_params(p), pt.o, pt.d, dot(pt.d, pt.d), closest_t, sphere_idx, stack, stride, tl);
     return segment_post<STATS>(fresh_params(p), pt, th, st, closest_t, sphere_idx, tl);
 }
 
-// One whole iteration of the bounce loop: traversal + everything else.
+// One whole iteration of the bounce loop: traversal + everything else.  MULTI = false: trees of at most one node AND no
+// sphere tree (k_trace's default instantiations).
 template <bool STATS, bool MULTI = true>
 DEV bool segment(const KParams& p, Path& pt, uint32_t* stack, uint32_t stride, Tally<STATS>& tl) {
     const TriHit th = intersect_bvh<STATS, MULTI>(fresh_params(p), pt.o, pt.d, stack, stride, tl);
-    return segment_finish<STATS>(p, pt, th, stack, stride, tl);
+    return segment_finish<STATS, MULTI>(p, pt, th, stack, stride, tl);
 }
 
 // ----------------------------------------------------------------- camera --

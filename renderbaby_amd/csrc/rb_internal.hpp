@@ -327,7 +327,7 @@ int launch_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uint3
                           uint32_t a_count, unsigned long long* mismatch16, void* stream);
 int launch_rcp_exhaustive(uint32_t expo, uint32_t* mismatch16, void* stream);
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream);
-int debug_sph_profile(unsigned long long* out16, int reset);   // pass occupancy of k_trace_sph in a -DRB_SPH_PROFILE build (-1 otherwise)
+int debug_walk_profile(unsigned long long* out64, int reset);   // pass occupancy counters of a profiling build, tools/ablate/rb_profile.patch (-1 otherwise)
 double measure_l1_gather(size_t table_bytes, uint32_t rounds);   // divergent 16-byte gathers from an L2-resident table: lane accesses / s
 int device_cu_count(int device);
 uint32_t stream_kernel_max_threads(uint32_t blocks_per_cu);  // upper bound of grid * block of the stream kernels

@@ -375,8 +375,8 @@ struct ItemQueue {
     }
 };
 
-// MULTI = false: trees of at most one node only (the default instantiation: launch_render sends every multi-node
-// tree to a stepped kernel); MULTI = true: the per-segment ablation of those (opt no_leaf_stepping).
+// MULTI = false: trees of at most one node and at most 64 spheres only (the default instantiation: launch_render sends every
+// multi-node tree and every sphere tree to a stepped kernel); MULTI = true: the per-segment ablation of those (opt no_leaf_stepping).
 // WAVES = resident waves per SIMD the register allocation aims for: 6 (80 registers, nothing spilled) except for the
 // large launches of the default instantiation, which run 3 % faster with 8 (64 registers, 9 spilled outside the
 // segment code) -- and 2-3 % slower on one-sample frames, hence two instantiations.
@@ -761,7 +761,9 @@ DEV bool chunk_node_step(const KParams& p, uint32_t* stack, uint32_t stride, f3 
     return true;
 }
 
-template <bool STATS>
+// SPHTREE: the instantiation for scenes that also have a sphere tree (more than 64 spheres), whose per-lane walk runs inside
+// segment_finish; the other one leaves that walk out of its register allocation
+template <bool STATS, bool SPHTREE>
 __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
@@ -953,7 +955,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_CHUNK_WAVES) k_trace_chunk(con
                     const v4f a = tp[0], b = tp[1], c = tp[2];
                     th.t = isect_triangle(pt.o, pt.d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), th.u, th.v);
                 }
-                const bool alive = segment_finish<STATS>(p, pt, th, stack, kTraceBlock, tl);
+                const bool alive = segment_finish<STATS, SPHTREE>(p, pt, th, stack, kTraceBlock, tl);
                 if (alive) {
                     state = BEGIN;
                 } else {
@@ -1123,12 +1125,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_FAST_WAVES) k_trace_fast(const
 #endif
 constexpr uint32_t kSphPerLane = RB_SPH_PER_LANE;
 static_assert(kSphPerLane == 1 || kSphPerLane == 2, "one or two spheres per lane and round");
-#ifdef RB_SPH_PROFILE
-__device__ unsigned long long g_sph_prof[16];
-#define SPH_PROF(i, v) prof[i] += (v)
-#else
-#define SPH_PROF(i, v)
-#endif
 constexpr uint32_t kSphWaveLds = 64u * 32u + 64u * 8u + 64u * 4u + 128u * 4u + 128u * 4u;   // per wave: ray records, best keys, a = d.d, units, survivors
 
 template <bool STATS>
@@ -1177,9 +1173,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
     int sp = 0;
     // a lane whose walk arrives at a leaf while it holds none aside keeps the leaf for the next leaf phase and goes on with
     // the subtree it had put aside (its best t is then one leaf behind: never wrong)
-#ifdef RB_SPH_PROFILE
-    unsigned long long prof[16] = {0};
-#endif
     auto set_aside = [&]() {
         if (state == TRAV && cur != kSphNone && (cur & 0x80000000u) != 0u && pend == kSphNone) {
             pend = cur;
@@ -1210,8 +1203,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             continue;
         }
 
-        SPH_PROF(0, 1);
-        { const uint32_t nb = (uint32_t)__popcll(__ballot(state == BEGIN)); if (nb) { SPH_PROF(1, 1); SPH_PROF(2, nb); } }
         // ---- (2) start of a segment: ground and the triangle list (shader.wgsl:552-571), then the root of the sphere tree
         if (state == BEGIN) {
             const KParams& fp = fresh_params(p);
@@ -1236,7 +1227,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             const bool at_node = state == TRAV && cur != kSphNone && (cur & 0x80000000u) == 0u;
             const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
             if (n == 0u || (it > 0 && n < (uint32_t)RB_SPH_NODE_LANES)) break;
-            SPH_PROF(3, 1); SPH_PROF(4, n);
             if (at_node) {
                 const uint32_t nxt = sphere_node_step(p, cur, pt.o, inv, dneg, rs, __uint_as_float((uint32_t)(key >> 32)), [&](uint32_t ref) {
                     stack[sp * kTraceBlock] = ref;
@@ -1265,7 +1255,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             const uint32_t n_node = (uint32_t)__popcll(__ballot(state == TRAV && cur != kSphNone && !lf));
             if (n_units != 0u && (n_units >= (uint32_t)RB_SPH_LEAF_LANES || n_node == 0u)) {
                 const unsigned long long below = (1ull << lane) - 1ull;
-                SPH_PROF(5, 1); SPH_PROF(6, n_units); SPH_PROF(7, (n_units + 64u * kSphPerLane / kSphLeaf - 1u) / (64u * kSphPerLane / kSphLeaf));
                 if (lp) units[(uint32_t)__popcll(mp & below)] = lane;
                 if (lf) units[n_pend + (uint32_t)__popcll(m & below)] = lane | 64u;
                 if (lf || lp) {
@@ -1283,7 +1272,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
                 // the survivors of the discriminant, 64 at a time (or what is left): the whole intersect_sphere
                 uint32_t n_cand = 0u;
                 auto flush = [&](uint32_t k) {
-                    SPH_PROF(8, 1); SPH_PROF(9, k);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (lane < k) {
@@ -1373,7 +1361,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
         {
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(state == FINISH));
             const uint32_t n_trav = (uint32_t)__popcll(__ballot(state == TRAV));
-            if (n_fin != 0u && (n_fin >= (uint32_t)RB_SPH_FINISH_LANES || n_trav == 0u)) { SPH_PROF(10, 1); SPH_PROF(11, n_fin); }
             if (n_fin != 0u && (n_fin >= (uint32_t)RB_SPH_FINISH_LANES || n_trav == 0u) && state == FINISH) {
                 float closest_t = st.closest_t;
                 uint32_t sphere_idx = 0xFFFFFFFFu;
@@ -1393,9 +1380,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
         }
     }
     flush_tally<STATS>(tl, p.counters);
-#ifdef RB_SPH_PROFILE
-    if (lane == 0u) for (int i = 0; i < 12; i++) atomicAdd(&g_sph_prof[i], prof[i]);
-#endif
 }
 
 // Phase 2: ordered accumulation + tone map + pack.  One wavefront per 8x8 tile,
@@ -1789,8 +1773,13 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
                 else hipLaunchKernelGGL(k_trace_sph<false>, grid, block, li.lds_bytes, stream, q);
                 break;
             case CHUNK:
-                if (stats) hipLaunchKernelGGL(k_trace_chunk<true>, grid, block, li.lds_bytes, stream, q);
-                else hipLaunchKernelGGL(k_trace_chunk<false>, grid, block, li.lds_bytes, stream, q);
+                if (p.sph_nodes != nullptr) {
+                    if (stats) hipLaunchKernelGGL((k_trace_chunk<true, true>), grid, block, li.lds_bytes, stream, q);
+                    else hipLaunchKernelGGL((k_trace_chunk<false, true>), grid, block, li.lds_bytes, stream, q);
+                } else {
+                    if (stats) hipLaunchKernelGGL((k_trace_chunk<true, false>), grid, block, li.lds_bytes, stream, q);
+                    else hipLaunchKernelGGL((k_trace_chunk<false, false>), grid, block, li.lds_bytes, stream, q);
+                }
                 break;
             case FAST:
                 if (stats) hipLaunchKernelGGL(k_trace_fast<true>, grid, block, lds, stream, q);
@@ -1810,7 +1799,7 @@ int launch_render(const KParams& p_, uint32_t kernel, bool stats, void* stream_,
                 else hipLaunchKernelGGL((k_trace_bvh<false, false, kTraceBlock>), grid, block, lds, stream, q);
                 break;
             case PLAIN:
-                if (p.u.bvh_node_count > 1u) {   // per-segment ablation of a multi-node tree
+                if (p.u.bvh_node_count > 1u || p.sph_nodes != nullptr) {   // per-segment ablation of a multi-node tree or of the sphere tree
                     if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, stream, q);
                     else hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, stream, q);
                 } else {
@@ -1925,19 +1914,11 @@ double measure_l1_gather(size_t table_bytes, uint32_t rounds) {
     return best;
 }
 
-int debug_sph_profile(unsigned long long* out16, int reset) {
-#ifdef RB_SPH_PROFILE
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sph_prof), 16 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        const unsigned long long z[16] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_sph_prof), z, sizeof(z));
-    }
-    return (int)e;
-#else
-    (void)out16; (void)reset;
-    return -1;
+// pass-occupancy counters of a profiling build (tools/ablate/rb_profile.patch defines RB_WALK_PROFILE and the counting);
+// the product build counts nothing
+#ifndef RB_WALK_PROFILE
+int debug_walk_profile(unsigned long long*, int) { return -1; }
 #endif
-}
 
 int launch_debug_math(const float* a, const float* b, float* out, uint32_t n, void* stream_) {
     if (n == 0) return 0;

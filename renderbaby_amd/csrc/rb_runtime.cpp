@@ -1829,11 +1829,11 @@ int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_
     return *accesses_per_s > 0.0 ? RB_OK : RB_ERR_DEVICE;
 }
 
-int rb_debug_walk_profile(uint64_t out16[16], int reset) {
-    if (!out16) return RB_ERR_NULL_ARGUMENT;
+int rb_debug_walk_profile(uint64_t out64[64], int reset) {
+    if (!out64) return RB_ERR_NULL_ARGUMENT;
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
     if (hipDeviceSynchronize() != hipSuccess) return RB_ERR_DEVICE;
-    return rb::debug_sph_profile(reinterpret_cast<unsigned long long*>(out16), reset) == 0 ? RB_OK : RB_ERR_DEVICE;
+    return rb::debug_walk_profile(reinterpret_cast<unsigned long long*>(out64), reset) == 0 ? RB_OK : RB_ERR_DEVICE;
 }
 
 // Debug hook for tests/test_gpu_parity.py: device /, sqrt, normalize, u32->f32, min/max, dot.

@@ -1,5 +1,5 @@
-"""Pass occupancy of k_trace_sph (a -DRB_SPH_PROFILE build: tools/build_variant.sh sphprof -DRB_SPH_PROFILE=1):
-   RB_LIBRARY_PATH=renderbaby_amd/variants/lib_sphprof.so python tools/sph_profile.py [c4|c4s] [spp] [host|device]"""
+"""Pass occupancy of k_trace_sph (a profiling build: tools/walk_profile.sh):
+   RB_LIBRARY_PATH=$PWD/renderbaby_amd/variants/lib_walkprof.so python tools/sph_profile.py [c4|c4s] [spp] [host|device]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from renderbaby_amd import Engine, RenderConfig, scenes, _lib
@@ -10,11 +10,11 @@ s = scenes.spheres_scene(1_000_000, 4096, 4096, spp, 5) if w == "c4" else scenes
 rc = RenderConfig.from_scene(s)
 eng = Engine.new(rc, stats=True, sphere_tree=tree); eng.update(rc)
 lib = _lib.load()
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 64)()
 eng.clear(); eng.dispatch(0, spp); eng.sync()
 lib.rb_debug_walk_profile(out, 1)
 eng.reset_stats(); eng.clear(); eng.dispatch(0, spp); eng.sync()
-assert lib.rb_debug_walk_profile(out, 1) == 0, "not a -DRB_SPH_PROFILE build"
+assert lib.rb_debug_walk_profile(out, 1) == 0, "not a profiling build (tools/walk_profile.sh)"
 st = eng.stats(); seg = st["segments"]
 it, bp, bl, npass, nl, lph, units, rounds, fl, cands, fp, fin = [out[i] for i in range(12)]
 print(f"{w} {spp} spp, tree {eng.sphere_tree_builder()}, {eng.last_kernel_name()} {eng.last_dispatch_ms():.1f} ms (counting build), segments {seg}")

@@ -693,7 +693,7 @@ DEV float max_abs(float a, float b) {
     return r;
 }
 
-// One child slot of a ChunkNode: enter it?  `order` = where the ray enters the inflated box (nearer child first).
+// One child slot of a ChunkNode: enter it?  `order` = where the ray enters the box as stored (nearer child first).
 // The slab values are the reference's (shader.wgsl:664-671 on the box as stored); the inflated box is derived from
 // them per axis -- a box grown by mm enters mm |1 / d| earlier and leaves as much later -- so one set of operations
 // serves the exact test and the conservative one.  NaN (0 * inf) always means "enter".
@@ -726,7 +726,10 @@ DEV bool chunk_child(v4f lo, v4f hi, uint32_t fac, v4f cone, bool exact, f3 o, f
     const float dt = fin ? sp_ * __builtin_fmaf(kChunkKT, f, kChunkKD) : 1e30f;
     const float tn = fmaxf(fmaxf(__builtin_fmaf(-mm, ix, nx), __builtin_fmaf(-mm, iy, ny)), __builtin_fmaf(-mm, iz, nz));
     const float tf = fminf(fminf(__builtin_fmaf(mm, ix, fx), __builtin_fmaf(mm, iy, fy)), __builtin_fmaf(mm, iz, fz));
-    order = tn;
+    // nearer child first by where the ray enters the box AS STORED, not the inflated one: a wide margin makes tn early for
+    // every child that has one and says little about which child the ray meets first (r04: C3 - 17 % triangle tests, - 9 %
+    // child tests, + 14 % segments/s; C5 + 6 %; any order is correct)
+    order = tmin;
     return !(tf < tn) && !(tf < -dt) && !(tn - dt > best_t);
 }
 

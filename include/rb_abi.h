@@ -254,7 +254,11 @@ enum {
                                    reference's own slab arithmetic (nearer child first, subtrees culled on the best t by the
                                    margin that bounds the reference's reported hits), the library's own levels below its
                                    leaves down to 16-triangle chunks, which a wavefront tests cooperatively, one triangle
-                                   per lane; same frames.  The flag only makes the choice explicit */
+                                   per lane.  Same frames: every hit goes through the reference's own
+                                   triangle test, and the two rounding-error inequalities the culling rests on are derived
+                                   mechanically (tools/margin_certify.py) and fuzzed against the oracle, not proven in a proof
+                                   assistant -- RB_FLAG_REFERENCE_WALK, or RB_REFERENCE_WALK=1 in the environment of a host that
+                                   cannot be rebuilt, walks the reference's way.  The flag only makes the choice explicit */
     RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
                                            (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be

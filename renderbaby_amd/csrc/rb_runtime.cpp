@@ -1115,6 +1115,12 @@ rb_engine* create_single(const rb_config* cfg, const rb_options& opt) {
     rb_engine* e = new rb_engine();
     e->device = dev;
     e->opt = opt;
+    // RB_REFERENCE_WALK=1 in the environment: every engine of this process walks meshes exactly as shader.wgsl:282-392 does,
+    // whatever the host program's flags say -- the escape hatch from the culled walks (whose exactness is derived and fuzzed,
+    // DESIGN.md section 4.2) that needs no rebuild of the host
+    if (const char* rw = std::getenv("RB_REFERENCE_WALK"); rw && rw[0] == '1')
+        e->opt.flags = (e->opt.flags & ~(RB_FLAG_FAST_BVH | RB_FLAG_DEVICE_BVH | RB_FLAG_DEVICE_LBVH | RB_FLAG_HOST_BVH | RB_FLAG_CHUNK_WALK |
+                                         RB_FLAG_SKIP_NEAR_DEGENERATE)) | RB_FLAG_REFERENCE_WALK;
     auto bail = [&](const char* what, hipError_t st) -> rb_engine* {
         fail(nullptr, RB_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(st));
         rb_destroy(e);

@@ -151,3 +151,55 @@ def test_the_culling_rule_keeps_the_worst_cases_of_the_search():
     ok, t, _ = mc.mt32(o, d, v0, e1, e2)
     assert ok.all()
     assert _rule_keeps(o, d, v0, e1, e2, v1, v2, t).all()
+
+
+def _tool(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_two_inequalities_follow_from_the_standard_model_of_rounding():
+    # tools/margin_certify.py: the error analysis of shader.wgsl:248-280 carried out in exact rational arithmetic -- no rays,
+    # no roundings sampled -- ends in comparisons between rationals; every one must hold with the kernel's constants
+    mcert = _tool("margin_certify")
+    for name, need, has in mcert.checks:
+        if has is None:
+            assert need >= mcert.Fr(95, 100), name
+        else:
+            assert need <= has, (name, float(need), float(has))
+    # the derivation reproduces the hand-made constants of DESIGN.md section 4.1 (E7) to the digit they were quoted with
+    assert abs(float(mcert.c1) - 11.27) < 0.02 and abs(float(mcert.c2) - 4.60) < 0.02
+    assert abs(float(mcert.c1t) - 10.27) < 0.02 and abs(float(mcert.c2t) - 4.60) < 0.02
+    # and the kernel's constants are the ones it was run against
+    src = open(os.path.join(ROOT, "renderbaby_amd", "csrc", "rb_kernels.hip")).read()
+    for k, v in (("kChunkKP", "12.0f"), ("kChunkKT", "11.0f"), ("kChunkKS", "24.0f"), ("kChunkKD", "16.0f")):
+        assert f"constexpr float {k} = {v} * 5.9604645e-8f * 1.01f;" in src, k
+    assert "constexpr float kChunkFMax = 1.5e5f;" in src
+
+
+def test_reported_sphere_hits_stay_within_the_sphere_walks_margin():
+    # tools/sphere_margin_check.py, a small dose: the reference's intersect_sphere in numpy float32 against exact values on
+    # near-tangent rays; the discriminant's error constant and both parts of the margin (profiles/r04_sphere_margin_check.txt: 60 M rays)
+    smc = _tool("sphere_margin_check")
+    rng = np.random.default_rng(5)
+    o, d, c, r = smc.batch(rng, 400_000)
+    t, disc, a = smc.sphere32(o, d, c, r)
+    o64, d64, c64 = [np.stack([x.astype(np.float64) for x in v]) for v in (o, d, c)]
+    r64 = r.astype(np.float64)
+    oc = o64 - c64
+    a_, hb, D2 = (d64 * d64).sum(0), (oc * d64).sum(0), (oc * oc).sum(0)
+    Df = np.maximum(np.sqrt(D2), r64)
+    rep = t > 0
+    assert rep.sum() > 100_000
+    E = np.abs(disc.astype(np.float64) - (hb * hb - a_ * (D2 - r64 * r64))) / (smc.U * a_ * Df * Df)
+    assert E[rep].max() < 26.0
+    b = np.sqrt(np.maximum(D2 - hb * hb / a_, 0.0))
+    tc, s = -hb / a_, np.sqrt(np.maximum(r64 * r64 - np.maximum(D2 - hb * hb / a_, 0.0), 0.0) / a_)
+    th = t.astype(np.float64)
+    along = np.maximum(np.maximum((tc - s) - th, th - (tc + s)), 0.0) * np.sqrt(a_) / Df
+    across = np.maximum(b - r64, 0.0) / Df
+    assert across[rep].max() < smc.K and along[rep].max() < smc.K
+    src = open(os.path.join(ROOT, "renderbaby_amd", "csrc", "rb_device_shade.hpp")).read()
+    assert "constexpr float kSphK = 1.25e-3f * 1.001f;" in src

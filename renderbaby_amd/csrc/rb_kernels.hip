@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(BLOCK, RB_BVH_WAVES) k_trace_bvh(const KParams
 #define RB_CHUNK_NODE_LANES 32   // keep stepping nodes while this many lanes are at one ...
 #endif
 #ifndef RB_CHUNK_NODE_STEPS
-#define RB_CHUNK_NODE_STEPS 5    // ... but at most this many steps per outer iteration
+#define RB_CHUNK_NODE_STEPS 8    // ... but at most this many steps per outer iteration (r04: 8 instead of 5, + 1..2 %)
 #endif
 #ifndef RB_CHUNK_LEAF_LANES
 #define RB_CHUNK_LEAF_LANES 8    // test chunks once this many lanes wait at one (or nobody is at a node)

@@ -28,6 +28,8 @@ pub const RB_FLAG_GATHER_PEER_COPY: u32 = 128;   // rb_create_multi without RCCL
 pub const RB_FLAG_NO_RUN_AHEAD: u32 = 256;       // iterator: no pass started ahead of the read-back
 pub const RB_FLAG_SKIP_NEAR_DEGENERATE: u32 = 512; // the library's tree without its second pass (outside the exactness argument)
 pub const RB_FLAG_CHUNK_WALK: u32 = 1024;        // the chunked walk: the default for multi-node meshes, the flag only names it
+pub const RB_FLAG_SPHERE_TREE_HOST: u32 = 2048;  // > 64 spheres: build the sphere tree on the host ...
+pub const RB_FLAG_SPHERE_TREE_DEVICE: u32 = 4096; // ... or on the device whatever the count (default: the device from 1024 spheres up)
 pub const RB_COMM_ID_BYTES: usize = 128;
 
 unsafe extern "C" {
@@ -35,7 +37,8 @@ unsafe extern "C" {
     pub fn rb_create_ex(cfg: *const RbConfig, opt: *const RbOptions) -> *mut RbEngine;
     /// one handle over several devices of this process: rows sharded in stripes, one RCCL gather per delivered frame
     pub fn rb_create_multi(cfg: *const RbConfig, opt: *const RbOptions, devices: *const i32, n_devices: u32) -> *mut RbEngine;
-    /// one process per device: rank 0 makes the id, every rank joins with its shard
+    /// one process per device: every rank asks whether RCCL loads at all (no id, no socket), rank 0 makes the id, every rank joins with its shard
+    pub fn rb_comm_available() -> c_int;
     pub fn rb_comm_unique_id(id_out: *mut u8) -> c_int;
     pub fn rb_comm_init_rank(e: *mut RbEngine, id: *const u8, rank: u32, nranks: u32) -> c_int;
     /// the communicator as RCCL reports it (0 ranks: nothing goes through RCCL) and this rank's share of the last gather
@@ -51,6 +54,8 @@ unsafe extern "C" {
     pub fn rb_iter_next(e: *mut RbEngine, rgba_out: *mut u8) -> c_int;
     pub fn rb_iter_destroy(e: *mut RbEngine);
     pub fn rb_iter_set_passes_per_frame(e: *mut RbEngine, n: u32) -> c_int;   // extension: a frame every n samples
+    /// optional: allocate what the first render of n_passes passes would allocate lazily (a host that times its first frame)
+    pub fn rb_reserve(e: *mut RbEngine, n_passes: u32) -> c_int;
     pub fn rb_get_size(e: *const RbEngine, w: *mut u32, h: *mut u32) -> c_int;
     pub fn rb_last_error(e: *const RbEngine) -> *const c_char;
 }

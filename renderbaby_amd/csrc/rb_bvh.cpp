@@ -865,53 +865,75 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
                       const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, ChunkTree& out) {
     out = ChunkTree{};
     if (node_count < 2 || index_len == 0 || ref_nodes[0].primitive_count > 0) return false;
-    // ---- the reference's visit order (right child first, shader.wgsl:376-387): ranks, and nodes parents-first
-    std::vector<uint32_t> order, st{0u}, leaf_rank0(node_count, 0u);
-    uint32_t rank = 0;
+    // one thread per CPU the process is granted (RB_HOST_BUILD_SEQUENTIAL=1: one thread, for debugging); fn(first, last)
+    const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
+    const size_t max_threads = (seq && seq[0] == '1') ? 1u : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t)>& fn) {
+        const size_t threads = std::min(std::min(max_threads, n), std::max<size_t>(index_len / 8192u, 1u));   // a thread per 8 192 slots: C3 gets 6, C5 all
+        if (threads <= 1) {
+            fn(0, n);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t per = (n + threads - 1) / threads;
+        for (size_t t = 0; t < threads; ++t) pool.emplace_back(fn, std::min(t * per, n), std::min((t + 1) * per, n));
+        for (std::thread& th : pool) th.join();
+    };
+    // ---- the reference's visit order (right child first, shader.wgsl:376-387): nodes parents-first, leaves in visit order
+    std::vector<uint32_t> order, st{0u}, leaves;
     while (!st.empty()) {
         const uint32_t ni = st.back();
         st.pop_back();
         order.push_back(ni);
+        if (order.size() > node_count) return false;
         const rb_bvh_node& n = ref_nodes[ni];
         if (n.primitive_count > 0) {
-            leaf_rank0[ni] = rank;
-            for (uint32_t i = 0; i < n.primitive_count; ++i) {
-                const uint32_t slot = n.first_primitive + i;
-                if (slot >= index_len || indices[slot] >= tri_count) continue;   // guards :331, :336
-                out.rank_slot.push_back(slot);
-                ++rank;
-            }
+            leaves.push_back(ni);
         } else {
             if (n.left < node_count) st.push_back(n.left);
             if (n.right < node_count) st.push_back(n.right);
         }
     }
-    if (rank == 0 || rank >= (1u << 26) - 64u || order.size() > node_count) return false;
+    // ranks: a leaf's first rank = the valid slots (guards :331, :336) of the leaves visited before it
+    auto valid = [&](uint32_t slot) { return slot < index_len && indices[slot] < tri_count; };
+    std::vector<uint32_t> leaf_rank0(leaves.size() + 1, 0u);
+    parallel_for(leaves.size(), [&](size_t first, size_t last) {
+        for (size_t li = first; li < last; ++li) {
+            const rb_bvh_node& n = ref_nodes[leaves[li]];
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < n.primitive_count; ++i) c += valid(n.first_primitive + i) ? 1u : 0u;
+            leaf_rank0[li + 1] = c;
+        }
+    });
+    for (size_t li = 0; li < leaves.size(); ++li) {
+        if (leaf_rank0[li] > (1u << 26)) return false;
+        leaf_rank0[li + 1] += leaf_rank0[li];
+    }
+    const uint32_t rank = leaf_rank0[leaves.size()];
+    if (rank == 0 || rank >= (1u << 26) - 64u) return false;
+    out.rank_slot.resize(rank);
     std::vector<ChunkInfo> info(node_count);
     // ---- the library's own levels below every reference leaf.  The leaves are independent, so they are built in parallel
     // (C5's 8 192 leaves of 128 triangles: 85 ms on one thread), each into arrays of its own with references that count from
     // zero; laid end to end afterwards, the references shifted by where a leaf's arrays landed.
-    std::vector<uint32_t> leaves;
-    for (uint32_t ni : order)
-        if (ref_nodes[ni].primitive_count > 0) leaves.push_back(ni);
     struct LeafOut {
         ChunkTree t;
         ChunkInfo info;
     };
     std::vector<LeafOut> lout(leaves.size());
-    auto build_range = [&](size_t first, size_t last) {
+    parallel_for(leaves.size(), [&](size_t first, size_t last) {
         std::vector<ChunkItem> items;
         for (size_t li = first; li < last; ++li) {
-            const uint32_t ni = leaves[li];
-            const rb_bvh_node& n = ref_nodes[ni];
+            const rb_bvh_node& n = ref_nodes[leaves[li]];
             items.clear();
-            uint32_t rk = leaf_rank0[ni];
+            uint32_t rk = leaf_rank0[li];
             for (uint32_t i = 0; i < n.primitive_count; ++i) {
                 const uint32_t slot = n.first_primitive + i;
-                if (slot >= index_len || indices[slot] >= tri_count) continue;
+                if (!valid(slot)) continue;
                 const rb_gpu_triangle& t = tris[indices[slot]];
                 ChunkItem it;
                 it.slot = slot;
+                out.rank_slot[rk] = slot;
                 it.rank = rk++;
                 double ll = 0, l2 = 0;
                 for (int a = 0; a < 3; ++a) {
@@ -934,50 +956,40 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             ChunkBuilder cb{lout[li].t, items};
             lout[li].info = cb.build_leaf(0, items.size());
         }
-    };
+    });
     {
-        const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
-        size_t threads = (seq && seq[0] == '1') ? 1u : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-        if (rank < 16384u) threads = 1;
-        threads = std::min(threads, leaves.size());
-        if (threads <= 1) {
-            build_range(0, leaves.size());
-        } else {
-            std::vector<std::thread> pool;
-            const size_t per = (leaves.size() + threads - 1) / threads;
-            for (size_t t = 0; t < threads; ++t)
-                pool.emplace_back(build_range, std::min(t * per, leaves.size()), std::min((t + 1) * per, leaves.size()));
-            for (std::thread& th : pool) th.join();
+        std::vector<uint32_t> node_off(leaves.size() + 1, 0u), pos_off(leaves.size() + 1, 0u);
+        for (size_t li = 0; li < leaves.size(); ++li) {
+            node_off[li + 1] = node_off[li] + static_cast<uint32_t>(lout[li].t.nodes.size());
+            pos_off[li + 1] = pos_off[li] + static_cast<uint32_t>(lout[li].t.pos_slot.size());
         }
-    }
-    {
-        size_t n_nodes = 0, n_pos = 0;
-        for (const LeafOut& l : lout) {
-            n_nodes += l.t.nodes.size();
-            n_pos += l.t.pos_slot.size();
-        }
+        const size_t n_nodes = node_off[leaves.size()], n_pos = pos_off[leaves.size()];
         if (n_pos >= (1u << 26) || n_nodes >= (1u << 30)) return false;
         out.nodes.reserve(n_nodes + order.size());
-        out.pos_slot.reserve(n_pos);
-        out.pos_rank.reserve(n_pos);
-        for (size_t li = 0; li < lout.size(); ++li) {
-            LeafOut& l = lout[li];
-            const uint32_t node_off = static_cast<uint32_t>(out.nodes.size()), pos_off = static_cast<uint32_t>(out.pos_slot.size());
-            auto moved = [&](uint32_t ref) {   // leaf: first position += pos_off; node: index += node_off
-                if (ref == kChunkNone) return ref;
-                return (ref & kChunkLeaf) ? ref + pos_off : ref + node_off;
-            };
-            for (ChunkNode c : l.t.nodes) {
-                c.lref = moved(c.lref);
-                c.rref = moved(c.rref);
-                out.nodes.push_back(c);
+        out.nodes.resize(n_nodes);
+        out.pos_slot.resize(n_pos);
+        out.pos_rank.resize(n_pos);
+        parallel_for(leaves.size(), [&](size_t first, size_t last) {
+            for (size_t li = first; li < last; ++li) {
+                LeafOut& l = lout[li];
+                const uint32_t no = node_off[li], po = pos_off[li];
+                auto moved = [&](uint32_t ref) {   // leaf: first position += po; node: index += no
+                    if (ref == kChunkNone) return ref;
+                    return (ref & kChunkLeaf) ? ref + po : ref + no;
+                };
+                for (size_t k = 0; k < l.t.nodes.size(); ++k) {
+                    ChunkNode c = l.t.nodes[k];
+                    c.lref = moved(c.lref);
+                    c.rref = moved(c.rref);
+                    out.nodes[no + k] = c;
+                }
+                std::copy(l.t.pos_slot.begin(), l.t.pos_slot.end(), out.pos_slot.begin() + po);
+                std::copy(l.t.pos_rank.begin(), l.t.pos_rank.end(), out.pos_rank.begin() + po);
+                l.info.ref = moved(l.info.ref);
+                info[leaves[li]] = l.info;
+                l.t = ChunkTree{};
             }
-            out.pos_slot.insert(out.pos_slot.end(), l.t.pos_slot.begin(), l.t.pos_slot.end());
-            out.pos_rank.insert(out.pos_rank.end(), l.t.pos_rank.begin(), l.t.pos_rank.end());
-            l.info.ref = moved(l.info.ref);
-            info[leaves[li]] = l.info;
-            l.t = ChunkTree{};
-        }
+        });
     }
     // ---- bottom-up over the caller's internal nodes: children before parents
     for (size_t k = order.size(); k-- > 0;) {

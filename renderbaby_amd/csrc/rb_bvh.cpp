@@ -29,31 +29,64 @@ namespace {
 
 constexpr size_t kMaxLeaf = 128;  // bvh.rs:12
 
+// BVH::new / build_node, bvh.rs:87-150, restated: bounds over the three vertices of every triangle of the range, a leaf at
+// <= 128 triangles, else the longest axis of those bounds (x only if strictly the longest, else y if longer than z, else z),
+// mid = first + count / 2, the range partitioned around the element of rank mid by centroid[axis] (select_nth_unstable_by:
+// std::nth_element here; the order inside the halves is unspecified there too), left then right, pre-order numbering.
+// The halves are independent, and a subtree's node count follows from its triangle count alone, so every node's index is
+// known before anything is built: the top levels fork threads (r04: C5's 10^6 triangles 133 -> ~ 25 ms on 16 CPUs; the
+// reference rebuilds this tree on the CPU for every render, scene_engine_adapter.rs:435-440).  Centroids and per-triangle
+// bounds are worked out once (the same f32 operations as bvh.rs:152-154 and aabb.rs), not once per comparison.
 struct Builder {
     const rb_gpu_triangle* tris;
     std::vector<uint32_t>& idx;
     std::vector<rb_bvh_node>& nodes;
+    std::vector<float> cen[3];       // centroid per triangle and axis
+    std::vector<float> tmn, tmx;     // bounds per triangle (3 floats each)
+    uint32_t fork_levels = 0;
 
     static float centroid(const rb_gpu_triangle& t, int axis) {
         return ((t.v0[axis] + t.v1[axis]) + t.v2[axis]) / 3.0f;  // bvh.rs:152-154
     }
+    static size_t nodes_of(size_t count) {   // nodes of the subtree over `count` triangles
+        return count <= kMaxLeaf ? 1 : 1 + nodes_of(count / 2) + nodes_of(count - count / 2);
+    }
+    void prepare(size_t n, size_t threads) {
+        for (int a = 0; a < 3; ++a) cen[a].resize(n);
+        tmn.resize(3 * n);
+        tmx.resize(3 * n);
+        auto work = [&](size_t first, size_t last) {
+            for (size_t i = first; i < last; ++i) {
+                const rb_gpu_triangle& t = tris[i];
+                for (int a = 0; a < 3; ++a) {
+                    cen[a][i] = centroid(t, a);
+                    tmn[3 * i + a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
+                    tmx[3 * i + a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
+                }
+            }
+        };
+        if (threads <= 1 || n < 65536) {
+            work(0, n);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t per = (n + threads - 1) / threads;
+        for (size_t t = 0; t < threads; ++t) pool.emplace_back(work, std::min(t * per, n), std::min((t + 1) * per, n));
+        for (std::thread& th : pool) th.join();
+    }
 
-    uint32_t node(size_t first, size_t count) {
-        const uint32_t me = static_cast<uint32_t>(nodes.size());
-        nodes.emplace_back();
+    void node(size_t first, size_t count, uint32_t me, uint32_t level) {
         float mn[3], mx[3];
         for (int a = 0; a < 3; ++a) {
             mn[a] = std::numeric_limits<float>::infinity();
             mx[a] = -std::numeric_limits<float>::infinity();
         }
         for (size_t i = first; i < first + count; ++i) {
-            const rb_gpu_triangle& t = tris[idx[i]];
-            const float* vs[3] = {t.v0, t.v1, t.v2};
-            for (auto v : vs)
-                for (int a = 0; a < 3; ++a) {
-                    mn[a] = std::min(mn[a], v[a]);
-                    mx[a] = std::max(mx[a], v[a]);
-                }
+            const size_t t = idx[i];
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], tmn[3 * t + a]);
+                mx[a] = std::max(mx[a], tmx[3 * t + a]);
+            }
         }
         rb_bvh_node n;
         std::memset(&n, 0, sizeof n);
@@ -63,19 +96,26 @@ struct Builder {
             n.first_primitive = static_cast<uint32_t>(first);
             n.primitive_count = static_cast<uint32_t>(count);
             nodes[me] = n;
-            return me;
+            return;
         }
         const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
         const int axis = (ex > ey && ex > ez) ? 0 : ((ey > ez) ? 1 : 2);  // bvh.rs:125-135
         const size_t mid = first + count / 2;
+        const float* c = cen[axis].data();
         std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
-                         [&](uint32_t a, uint32_t b) { return centroid(tris[a], axis) < centroid(tris[b], axis); });
-        const uint32_t l = node(first, mid - first);
-        const uint32_t r = node(mid, first + count - mid);
+                         [c](uint32_t a, uint32_t b) { return c[a] < c[b]; });
+        const uint32_t l = me + 1u, r = me + 1u + static_cast<uint32_t>(nodes_of(mid - first));
         n.left = l;
         n.right = r;
         nodes[me] = n;
-        return me;
+        if (level < fork_levels && count >= 32768) {
+            std::thread left([&] { node(first, mid - first, l, level + 1); });
+            node(mid, first + count - mid, r, level + 1);
+            left.join();
+        } else {
+            node(first, mid - first, l, level + 1);
+            node(mid, first + count - mid, r, level + 1);
+        }
     }
 };
 
@@ -87,9 +127,13 @@ void bvh_build(const rb_gpu_triangle* tris, size_t n_tris, std::vector<rb_bvh_no
     indices.resize(n_tris);
     for (size_t i = 0; i < n_tris; ++i) indices[i] = static_cast<uint32_t>(i);
     if (n_tris == 0) return;  // the adapter never builds an empty tree (scene_engine_adapter.rs:435-440)
-    nodes.reserve(2 * (n_tris / (kMaxLeaf / 2) + 1));
-    Builder b{tris, indices, nodes};
-    b.node(0, n_tris);
+    const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
+    const size_t threads = (seq && seq[0] == '1') ? 1u : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    Builder b{tris, indices, nodes, {}, {}, {}, 0};
+    for (size_t t = 1; t < threads; t *= 2) b.fork_levels++;   // 2^levels subtrees in flight
+    b.prepare(n_tris, threads);
+    nodes.resize(Builder::nodes_of(n_tris));
+    b.node(0, n_tris, 0u, 0u);
 }
 
 // Iterative DFS from node 0 following exactly the children the shader would push
@@ -869,7 +913,7 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
     const char* seq = std::getenv("RB_HOST_BUILD_SEQUENTIAL");
     const size_t max_threads = (seq && seq[0] == '1') ? 1u : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
     auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t)>& fn) {
-        const size_t threads = std::min(std::min(max_threads, n), std::max<size_t>(index_len / 8192u, 1u));   // a thread per 8 192 slots: C3 gets 6, C5 all
+        const size_t threads = (index_len < 16384u) ? 1u : std::min(max_threads, n);   // (C3's 50 176 slots: 1.9 ms on all threads, 3.3 ms on six)
         if (threads <= 1) {
             fn(0, n);
             return;

@@ -557,8 +557,8 @@ __global__ void __launch_bounds__(256) k_ms_emit(uint32_t n, uint32_t L, uint32_
     auto child = [&](int k, uint32_t cl, uint32_t cs) {   // slot k = segment cs of level cl
         const uint32_t h = (1u << cl) - 1u + cs;
         const float4 lo = hmin[h], hi = hmax[h];
-        nd.lox[k] = lo.x; nd.loy[k] = lo.y; nd.loz[k] = lo.z;
-        nd.hix[k] = hi.x; nd.hiy[k] = hi.y; nd.hiz[k] = hi.z;
+        const float l3[3] = {lo.x, lo.y, lo.z}, h3[3] = {hi.x, hi.y, hi.z};
+        nd.set_box(k, l3, h3);
         if (cl == L) {
             const uint32_t first = ms_start(cs, n, L), cnt = ms_start(cs + 1u, n, L) - first;
             nd.ref[k] = kLeafTag | ((cnt - 1u) << 27) | first;

@@ -255,8 +255,7 @@ struct SBuilder {
     void set_child(SphereNode4& n, int k, size_t first, size_t count, uint32_t ref) const {
         float mn[3], mx[3];
         bounds(first, count, mn, mx);
-        n.lox[k] = mn[0]; n.loy[k] = mn[1]; n.loz[k] = mn[2];
-        n.hix[k] = mx[0]; n.hiy[k] = mx[1]; n.hiz[k] = mx[2];
+        n.set_box(k, mn, mx);
         n.ref[k] = ref;
     }
     // returns a child reference: a leaf (count <= kSphLeaf) or the index of a node over two levels of splits

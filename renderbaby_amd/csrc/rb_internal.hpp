@@ -9,6 +9,12 @@
 
 #include "../../include/rb_abi.h"
 
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RB_HD __host__ __device__
+#else
+#define RB_HD
+#endif
+
 namespace rb {
 
 constexpr uint32_t kStackDepth = 32;      // per-lane traversal stack entries (LDS)
@@ -53,10 +59,21 @@ constexpr uint32_t kSphLeaf = RB_SPH_LEAF;   // spheres per leaf = lanes per (ra
 static_assert(kSphLeaf == 8 || kSphLeaf == 16, "a sphere leaf is tested by 8 or 16 lanes");
 constexpr uint32_t kSphNone = 0xFFFFFFFFu;
 struct alignas(16) SphereNode4 {
-    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];   // child k's box: (lox[k], loy[k], loz[k]) .. (hix[k], hiy[k], hiz[k])
+    float cx[4], cy[4], cz[4], hx[4], hy[4], hz[4];   // child k's box: centre (cx[k], cy[k], cz[k]) -+ half extents (hx[k], hy[k], hz[k]), rounded outwards
     uint32_t ref[4];   // child reference: kSphNone | node index | leaf = 0x80000000 | (count-1) << 27 | first (count <= kSphLeaf)
     uint32_t axes;     // children 0,1 = the lower half of the split along axis (axes & 3), cut along (axes >> 2) & 3; children 2,3 = the
     uint32_t _pad[3];  // upper half, cut along (axes >> 4) & 3: a ray visits the halves, and the children of a half, in the order of its direction's signs
+    // lo .. hi -> centre and half extents that contain it whatever the rounding (the slab test then costs 6 operations per axis instead of 8)
+    RB_HD void set_box(int k, const float lo[3], const float hi[3]) {
+        float* c[3] = {cx, cy, cz};
+        float* h[3] = {hx, hy, hz};
+        for (int a = 0; a < 3; ++a) {
+            const float m = 0.5f * lo[a] + 0.5f * hi[a];
+            const float d0 = m - lo[a], d1 = hi[a] - m, d = d0 > d1 ? d0 : d1;
+            c[a][k] = m;
+            h[a][k] = d >= 0.0f ? d * 1.0000004f + 1e-37f : 0.0f;   // (d rounded up: one ulp for the subtraction, one for this product)
+        }
+    }
 };
 static_assert(sizeof(SphereNode4) == 128, "SphereNode4 is 128 B");
 constexpr uint32_t kSphereBvhThreshold = 64;  // use the linear two-pass scan up to this many spheres

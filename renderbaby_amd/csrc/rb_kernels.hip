@@ -1170,7 +1170,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
     st.uvx = st.uvy = 0.0f;
     st.use_tex = st.tri_won_a = false;
     f3 inv = mk(0, 0, 0);
-    float aa = 1.0f, rs = 1.0f;
+    float aa = 1.0f;
     uint32_t dneg = 0u;
     unsigned long long key = 0ull;
     int sp = 0;
@@ -1214,7 +1214,6 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             // (1 / d only steers the walk: the hardware's reciprocal, within 1 ulp; the margin of sphere_child allows for it)
             inv = mk(__builtin_amdgcn_rcpf(pt.d.x), __builtin_amdgcn_rcpf(pt.d.y), __builtin_amdgcn_rcpf(pt.d.z));
             aa = dot(pt.d, pt.d);
-            rs = 1.001f * __builtin_amdgcn_rsqf(aa);
             dneg = sph_dir_signs(pt.d);
             key = (unsigned long long)__float_as_uint(st.closest_t) << 32;
             cur = fp.sph_root;
@@ -1231,7 +1230,7 @@ __global__ void __launch_bounds__(kTraceBlock, RB_SPH_WAVES) k_trace_sph(const K
             const uint32_t n = (uint32_t)__popcll(__ballot(at_node));
             if (n == 0u || (it > 0 && n < (uint32_t)RB_SPH_NODE_LANES)) break;
             if (at_node) {
-                const uint32_t nxt = sphere_node_step(p, cur, pt.o, inv, dneg, rs, __uint_as_float((uint32_t)(key >> 32)), [&](uint32_t ref) {
+                const uint32_t nxt = sphere_node_step(p, cur, pt.o, inv, dneg, __uint_as_float((uint32_t)(key >> 32)), [&](uint32_t ref) {
                     stack[sp * kTraceBlock] = ref;
                     sp++;
                 });

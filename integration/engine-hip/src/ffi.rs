@@ -57,5 +57,8 @@ unsafe extern "C" {
     /// optional: allocate what the first render of n_passes passes would allocate lazily (a host that times its first frame)
     pub fn rb_reserve(e: *mut RbEngine, n_passes: u32) -> c_int;
     pub fn rb_get_size(e: *const RbEngine, w: *mut u32, h: *mut u32) -> c_int;
+    /// BVH::new (engine-bvh/src/bvh.rs:87-150) restated, its top levels forked onto threads: the tree the adapter rebuilds per render
+    /// (scene_engine_adapter.rs:435-440) in a tenth of the time.  Two calls: nodes_out = null asks for the sizes.
+    pub fn rb_bvh_build(tris: *const c_void, n_tris: usize, nodes_out: *mut c_void, nodes_capacity: usize, n_nodes: *mut usize, indices_out: *mut u32) -> c_int;
     pub fn rb_last_error(e: *const RbEngine) -> *const c_char;
 }

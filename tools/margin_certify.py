@@ -1,4 +1,5 @@
-"""Machine-checked derivation of the two inequalities the chunked walk culls with (rb_kernels.hip chunk_child).
+"""Machine-checked derivation of the inequalities the culled walks rest on: the two of the chunked walk (rb_kernels.hip chunk_child;
+DESIGN.md 4.1 / 4.2) and, at the end, the sphere walks' (rb_device_shade.hpp sphere_child).
 
     Claim.  Let the reference's triangle test (shader.wgsl:248-280: every operation one IEEE binary32 operation, round to
     nearest, no FMA; dot = (x x' + y y') + z z'; f = the correctly rounded 1 / a) ACCEPT a hit of the triangle (v0, e1, e2)
@@ -161,6 +162,40 @@ checks.append(("cone bound: (1 - eta) |d| >= 0.95", Fr(95, 100), (1 - eta) * D_m
 checks.append(("determinant floor: |a^| >= 0.95 |a| under H3", 1 / kappa(lam_max), None))
 
 
+# =====================================================================================================================
+# The sphere walks (rb_device_shade.hpp sphere_child, kSphK): intersect_sphere's discriminant, shader.wgsl:193-199,
+#   oc^ = fl(o - c);  hb^ = dot3(oc^, d);  cc^ = fl(dot3(oc^, oc^) - fl(r r));  disc^ = fl(fl(hb^ hb^) - fl(a^ cc^)),  a^ = dot3(d, d)
+# |disc^ - disc*| <= E u a Dm^2 with Dm = max(|o - c|, r), a = |d|^2.  Everything below in units of a Dm^2 (|oc| <= Dm, r <= Dm).
+E_oc = u                                                    # |oc^ - oc| <= u |oc|
+N_oc = 1 + u
+# hb: rounding of the dot product on (oc^, d) with |r| <= |hb| + propagation, propagation |oc^ - oc| |d|       [units: Dm |d|]
+prop_hb = E_oc
+E_hb = (gamma(2) * N_oc + u1 * (1 + prop_hb)) / (1 - u1) + prop_hb
+# hb^2: |hb^^2 - hb^2| <= 2 |hb| E_hb + E_hb^2, then one rounding of the product                                   [units: a Dm^2]
+E_hb2 = (2 * E_hb + E_hb * E_hb) * (1 + u) + u
+# oc^ . oc^ against |oc|^2: rounding (gamma2 + u1) |oc^|^2 / (1 - u1), propagation (2 u + u^2) |oc|^2                 [units: Dm^2]
+E_oo = (gamma(2) + u1) * N_oc * N_oc / (1 - u1) + (2 * u + u * u)
+# cc^ = fl(oo^ - fl(r r)): u r^2 for the product, u |oo^ - rr^| <= u (1 + E_oo + u) max(|oc|^2, r^2) for the difference
+E_cc = E_oo + u + u * (1 + E_oo + u)
+# a^ cc^: |a^ - a| <= (gamma2 + u1) / (1 - u1) a;  |cc*| <= Dm^2;  one rounding of the product
+E_a = (gamma(2) + u1) / (1 - u1)
+E_ac = (E_a * 1 + (1 + E_a) * E_cc) * (1 + u) + u * (1 + E_cc)
+# the final difference: both errors, and one rounding of |hb^^2 - (a cc)^| <= (1 + E_hb2) + (1 + E_ac)
+E_disc = E_hb2 + E_ac + u * (2 + E_hb2 + E_ac)
+E_sphere = E_disc / u
+# what the walk needs (rb_device_shade.hpp): a reported hit has disc^ >= 0, so b^2 <= r^2 + E u Dm^2 (b: line to centre) and the reported
+# root is within sqrt(E u) Dm / |d| of the chord.  Beside that: |hb^ - hb| / a in t_c (E_hb Dm), the two roundings and the division of
+# the root (gamma(3) (|t_c| + s) |d| <= gamma(3) 2 Dm), the kernel's slab values (fl(c - o), an approximate reciprocal within 1 ulp, a
+# product: gamma(3) + u on |c - o| <= D) and the outward rounding of the stored boxes (inside D's factor 1.0000004): all relative to D >= Dm
+import math
+sqrtEu = Fr(math.isqrt(int(E_disc * 10 ** 30)) + 1, 10 ** 15)          # > sqrt(E u), a rational upper bound
+assert sqrtEu * sqrtEu > E_disc
+k_need = sqrtEu + E_hb + 2 * gamma(3) + (gamma(3) + 2 * u)
+k_has = Fr(125, 100000) * Fr(1001, 1000)                               # kSphK = 1.25e-3f * 1.001f (|d| = 1 +- 4 u and v_sqrt's ulp are in the 1.001)
+k_has_eff = k_has / (1 + 5 * u) / (1 + 2 * u)
+checks.append(("sphere: sqrt(E u) + the rest <= kSphK", k_need, k_has_eff))
+
+
 def main():
     f = lambda x: f"{float(x):.4f}"
     print("u = 2^-24;  units below: u for the constants, 1 for ratios")
@@ -170,6 +205,7 @@ def main():
     print(f"  across:  dist(Q*, box) <= u F |d| ({f(c1)} s + {f(c2)} L) + u ({f(c3)} s + {f(c4)} L)     [DESIGN r03 by hand: 11.2 s + 4.6 L; 10 u L]")
     print(f"  along:   |d||t^ - t*|  <= u F |d| ({f(c1t)} s + {f(c2t)} L) + u ({f(c3t)} s + {f(c4t)} L)     [DESIGN r03 by hand: 10.2 s + 4.6 L; 4 u t^]")
     print(f"  kernel:  slab planes misplaced by <= {f(k_slab)} u S;  the along comparison loses <= {f(k_cmp)} u S")
+    print(f"  spheres: |disc^ - disc*| <= {f(E_sphere)} u a max(|o - c|, r)^2   (assumed < 26 by kSphK; sampled: 8.9)   sqrt(E u) = {float(sqrtEu):.4e}")
     ok = True
     print("\n  check                                              needs      has        used")
     for name, need, has in checks:
@@ -178,9 +214,10 @@ def main():
             print(f"  {name:50s} {f(need)}  >= 0.95    {'ok' if good else 'FAIL'}")
         else:
             good = need <= has
-            print(f"  {name:50s} {f(need):>8s}   {f(has):>8s}   {float(need / has):6.3f}   {'ok' if good else 'FAIL'}")
+            fmt = (lambda x: f"{float(x):.4e}") if float(has) < 0.01 else f
+            print(f"  {name:50s} {fmt(need):>8s}   {fmt(has):>8s}   {float(need / has):6.3f}   {'ok' if good else 'FAIL'}")
         ok &= good
-    print("\nPASS: every accepted hit lies inside what chunk_child keeps, for every ray and triangle that meet H1-H4" if ok else "\nFAIL")
+    print("\nPASS: every accepted hit lies inside what chunk_child keeps, for every ray and triangle that meet H1-H4;\n      every reported sphere hit inside what sphere_child keeps (normalised directions, no underflow)" if ok else "\nFAIL")
     return 0 if ok else 1
 
 

@@ -67,8 +67,10 @@ DEV bool near_zero(f3 v) {                                                // :46
 //    smallest t below the incoming closest_t, ties going to the lowest index: here
 //    `t < best || (t == best && id < best_id)`;
 //  * a subtree is skipped only if no sphere below it can be REPORTED hit nearer than the best t so far.  The reference's
-//    discriminant hb^2 - a (|oc|^2 - r^2) carries an absolute error <= E u a D^2 (u = 2^-24; D >= max(|oc|, r); E < 24:
-//    tools/sphere_margin_check.py measures 8.9 at most over 43 M reported hits, a first-order count gives 20), so
+//    discriminant hb^2 - a (|oc|^2 - r^2) carries an absolute error <= E u a D^2 (u = 2^-24; D >= max(|oc|, r)) with E <= 22.0:
+//    tools/margin_certify.py derives it -- the standard model of rounding through the seven operations, in exact rational
+//    arithmetic -- and checks that sqrt(E u) plus everything else the walk can lose stays below kSphK (92 % of it);
+//    tools/sphere_margin_check.py samples 8.9 at most over 43 M reported hits.  So
 //      across the ray: a sphere is reported hit only by a ray whose LINE passes within r + sqrt(E u) D of its centre:
 //        the line's point nearest the centre (parameter t_c) lies in the sphere's box grown by mm = kSphK D;
 //      along the ray: the reported t^ = t_c -+ sqrt(disc^) / a is within dt = kSphK D / |d| of a point of the chord

@@ -89,3 +89,19 @@ def test_entry_points_reject_a_null_engine_without_touching_the_gpu():
     assert lib.rb_debug_walk_profile(None, 0) != 0
     lib.rb_iter_destroy(null)
     lib.rb_destroy(null)
+
+
+def test_one_stripe_default_everywhere():
+    # bench.py defaulted to 1-row stripes, the library and dist.py to 16; profiles/r04_shard_rehearsal.txt picked 8 for all
+    from renderbaby_amd import dist
+    lib = _lib.load()
+    assert dist.DEFAULT_STRIPE_ROWS == 8
+    for h, world in ((37, 2), (1080, 8), (2160, 3)):
+        for rank in range(world):
+            a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+            assert lib.rb_shard_layout(h, rank, world, 0, C.byref(a), C.byref(b)) == 0      # 0 = the library's default
+            assert lib.rb_shard_layout(h, rank, world, 8, C.byref(c), C.byref(d)) == 0
+            assert (a.value, b.value) == (c.value, d.value)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--stripe-rows", type=int, default=8' in src
+    assert "constexpr uint32_t kDefaultStripeRows = 8;" in open(os.path.join(ROOT, "renderbaby_amd", "csrc", "rb_internal.hpp")).read()

@@ -13,7 +13,7 @@ NUMERICS := -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(NUMERICS) -fno-slp-vectorize -Wall -Wno-unused-function
 SRCS     := $(CSRC)/rb_kernels.hip $(CSRC)/rb_build.hip $(CSRC)/rb_runtime.cpp $(CSRC)/rb_bvh.cpp $(CSRC)/rb_rccl.cpp
 HDRS     := $(CSRC)/rb_internal.hpp $(CSRC)/rb_device_common.hpp $(CSRC)/rb_device_math.hpp \
-            $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp $(CSRC)/rb_rccl.hpp include/rb_abi.h
+            $(CSRC)/rb_device_intersect.hpp $(CSRC)/rb_device_shade.hpp $(CSRC)/rb_rccl.hpp $(CSRC)/rb_chunk_math.hpp include/rb_abi.h
 OBJS     := $(patsubst $(CSRC)/%,build/obj/%.o,$(SRCS))
 
 all: $(OUT) oracle

@@ -259,6 +259,10 @@ enum {
                                    mechanically (tools/margin_certify.py) and fuzzed against the oracle, not proven in a proof
                                    assistant -- RB_FLAG_REFERENCE_WALK, or RB_REFERENCE_WALK=1 in the environment of a host that
                                    cannot be rebuilt, walks the reference's way.  The flag only makes the choice explicit */
+    RB_FLAG_CHUNK_TREE_HOST = 8192u,    /* the chunked walk's tree: build it on the host (one thread per granted CPU) ... */
+    RB_FLAG_CHUNK_TREE_DEVICE = 16384u, /* ... or on the device (one thread block per reference leaf) whatever the mesh's size; by default the
+                                           device builds it from 16 384 triangle slots up.  A caller's tree with leaves of more than 256
+                                           triangles is built on the host either way.  The frame does not depend on the builder. */
     RB_FLAG_SKIP_NEAR_DEGENERATE = 512u /* with the library's tree: skip its second pass.  The walk then answers only for
                                            hits whose ray is more than ~1.7 degrees off the plane of a LARGE triangle
                                            (L^2 > 1.6e-2); a hit the reference reports from a near-zero determinant there can be
@@ -442,6 +446,14 @@ int rb_bvh_build(const rb_gpu_triangle* tris, size_t n_tris,
  * margin}; a violated invariant is RB_ERR_INVALID_BVH with rb_last_error(NULL) naming it. */
 int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh_node* nodes, size_t n_nodes, const uint32_t* indices,
                         size_t n_indices, uint64_t out6[6]);
+/* The same check on the tree an engine is walking (after the first rb_dispatch / rb_render that follows an update): the
+ * chunked walk's arrays are read back from the device -- whichever builder made them -- and checked against the engine's
+ * copy of the mesh.  out6 as above (built = 0: the engine has no chunked tree). */
+int rb_debug_engine_chunk_tree(rb_engine* e, uint64_t out6[6]);
+/* Which builder produced the chunked walk's tree: "device", "host", or "" when the engine walks another way.  Valid after the
+ * first rb_dispatch / rb_render that follows an update; `build_ms`, if not NULL, receives the wall time of that build with
+ * its uploads and the gather of the chunks' triangle records. */
+const char* rb_chunk_tree_builder(const rb_engine* e, float* build_ms);
 /* Measurement aid for the roofline record (bench.py): the rate at which this device serves divergent 16-byte gathers --
  * every lane its own 128-byte line of a table of `table_bytes` (0 = 2 MiB, L2-resident) -- in lane accesses per second:
  * the ceiling of the L1 / texture-address path that a lane-per-ray tree walk runs into. */

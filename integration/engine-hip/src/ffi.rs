@@ -30,6 +30,8 @@ pub const RB_FLAG_SKIP_NEAR_DEGENERATE: u32 = 512; // the library's tree without
 pub const RB_FLAG_CHUNK_WALK: u32 = 1024;        // the chunked walk: the default for multi-node meshes, the flag only names it
 pub const RB_FLAG_SPHERE_TREE_HOST: u32 = 2048;  // > 64 spheres: build the sphere tree on the host ...
 pub const RB_FLAG_SPHERE_TREE_DEVICE: u32 = 4096; // ... or on the device whatever the count (default: the device from 1024 spheres up)
+pub const RB_FLAG_CHUNK_TREE_HOST: u32 = 8192;    // the chunked walk's tree: built on the host ...
+pub const RB_FLAG_CHUNK_TREE_DEVICE: u32 = 16384; // ... or on the device whatever the size (default: the device from 16 384 triangle slots up)
 pub const RB_COMM_ID_BYTES: usize = 128;
 
 unsafe extern "C" {

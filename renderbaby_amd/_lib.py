@@ -81,6 +81,8 @@ def load():
         "rb_last_kernel_name": (C.c_char_p, [vp]),
         "rb_fast_bvh_builder": (C.c_char_p, [vp, vp]),
         "rb_sphere_tree_builder": (C.c_char_p, [vp, vp]),
+        "rb_chunk_tree_builder": (C.c_char_p, [vp, vp]),
+        "rb_debug_engine_chunk_tree": (i32, [vp, vp]),
         "rb_version": (C.c_char_p, []),
         "rb_device_name": (i32, [i32, C.c_char_p, sz]),
     }
@@ -110,4 +112,4 @@ EXPORTS = ["rb_create", "rb_create_ex", "rb_create_multi", "rb_comm_available", 
            "rb_iter_begin", "rb_iter_has_next", "rb_iter_next", "rb_iter_destroy", "rb_iter_set_passes_per_frame", "rb_last_error",
            "rb_get_size", "rb_clear", "rb_dispatch", "rb_reserve", "rb_sync", "rb_read_rgba", "rb_read_accumulation",
            "rb_device_rgba", "rb_host_alloc", "rb_host_free", "rb_local_rows", "rb_global_row", "rb_shard_layout", "rb_shard_global_row", "rb_get_stats", "rb_reset_stats",
-           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_walk_profile", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_sphere_tree_builder", "rb_version", "rb_device_name"]
+           "rb_last_dispatch_ms", "rb_bvh_build", "rb_debug_chunk_tree", "rb_measure_l1_gather", "rb_debug_math", "rb_debug_walk_profile", "rb_debug_rcp_exhaustive", "rb_debug_div_exhaustive", "rb_last_kernel_name", "rb_fast_bvh_builder", "rb_sphere_tree_builder", "rb_chunk_tree_builder", "rb_debug_engine_chunk_tree", "rb_version", "rb_device_name"]

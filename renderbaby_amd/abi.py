@@ -73,6 +73,8 @@ FLAG_SKIP_NEAR_DEGENERATE = 512
 FLAG_CHUNK_WALK = 1024
 FLAG_SPHERE_TREE_HOST = 2048
 FLAG_SPHERE_TREE_DEVICE = 4096
+FLAG_CHUNK_TREE_HOST = 8192
+FLAG_CHUNK_TREE_DEVICE = 16384
 COMM_ID_BYTES = 128
 
 

@@ -28,6 +28,7 @@
 #include <utility>
 
 #include "rb_internal.hpp"
+#include "rb_chunk_math.hpp"
 
 #pragma clang fp contract(off)
 
@@ -660,6 +661,407 @@ int device_sphere_bvh_build(const rb_sphere* spheres, uint32_t n, SphereNode4* n
         info_out->n_nodes = static_cast<uint32_t>(sphere_tree_node_capacity(n));
     }
     return done(e);
+}
+
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------
+// The chunked walk's tree on the device.  What rb_bvh.cpp chunk_tree_build does per reference leaf
+// -- triangles whose determinant-floor bound is far above the leaf's median split off, median splits of the rest down to
+// chunks of kChunkTris, per-slot boxes, margins and cones -- one thread block does for one leaf here, the leaf's triangles
+// in LDS: a reference leaf holds at most 128 triangles (bvh.rs:12), a caller's own tree with leaves beyond
+// kChunkDeviceLeafMax goes to the host builder.  The arithmetic is rb_chunk_math.hpp's, the same source the host builder
+// compiles; the two trees differ only in how equal sort keys fall.  Two launches: <true> counts every leaf's valid
+// slots and nodes (scanned into each leaf's first rank / first node), <false> builds in place.  The caller's own internal
+// nodes (reference boxes, kChunkExact) are made by the host's bottom-up pass from the per-leaf summaries read back
+// (chunk_top_pass): 8 191 nodes for C5's 10^6 triangles.
+constexpr uint32_t kChunkDevBlock = 128;
+constexpr uint32_t kChunkDevTMax = 2u * (kChunkDeviceLeafMax / kChunkTris + 10u);   // tree entries of one leaf: chunks <= count / 16 + one per split-off set (<= 9)
+constexpr uint32_t kChunkDevSets = 12;
+
+struct ChunkDevT {   // one entry of the leaf's tree while it is made: items [lo, hi) of the current order
+    uint16_t lo, hi, k;      // k = chunks below (1 = a chunk)
+    int16_t left, right;     // entries (-1: not split yet / a chunk)
+    uint16_t level, ord;     // depth below the leaf's root; ordinal among the inner entries (= node index - the leaf's first)
+    uint16_t inner;
+};
+
+// ascending bitonic sort of (key, val) pairs in LDS; n2 a power of two; every thread of the block calls it
+__device__ void chunk_bitonic(unsigned long long* key, uint32_t* val, uint32_t n2, uint32_t t) {
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < n2; i += kChunkDevBlock) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const unsigned long long a = key[i], b = key[x];
+                    if ((a > b) == ((i & k) == 0u)) {
+                        key[i] = b;
+                        key[x] = a;
+                        const uint32_t v = val[i];
+                        val[i] = val[x];
+                        val[x] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kChunkDevBlock) k_chunk_leaves(const rb_gpu_triangle* __restrict__ tris, uint32_t tri_count,
+                                                                 const uint32_t* __restrict__ indices, uint32_t index_len,
+                                                                 const uint2* __restrict__ leaf_desc, uint32_t n_leaves,
+                                                                 uint32_t* __restrict__ leaf_valid, uint32_t* __restrict__ leaf_nodes,
+                                                                 const uint32_t* __restrict__ rank0, const uint32_t* __restrict__ node0,
+                                                                 ChunkNode* __restrict__ nodes, uint32_t* __restrict__ pos_slot,
+                                                                 uint32_t* __restrict__ pos_rank, uint32_t* __restrict__ rank_slot,
+                                                                 chunkmath::ChunkInfo* __restrict__ leaf_info) {
+    using chunkmath::ChunkInfo;
+    using chunkmath::ChunkItem;
+    __shared__ ChunkItem items[kChunkDeviceLeafMax];
+    __shared__ unsigned long long key[kChunkDeviceLeafMax];
+    __shared__ uint32_t perm[kChunkDeviceLeafMax];
+    __shared__ uint32_t slots[kChunkDeviceLeafMax];
+    __shared__ uint8_t segof[kChunkDeviceLeafMax];
+    __shared__ ChunkDevT tn[kChunkDevTMax];
+    __shared__ alignas(8) unsigned char info_raw[sizeof(ChunkInfo) * kChunkDevTMax];   // (ChunkInfo has default member initialisers)
+    ChunkInfo* info = reinterpret_cast<ChunkInfo*>(info_raw);
+    __shared__ uint16_t pend[kChunkDevTMax], pend_next[kChunkDevTMax];
+    __shared__ uint8_t pend_axis[kChunkDevTMax];
+    __shared__ uint16_t set_lo[kChunkDevSets], set_hi[kChunkDevSets];
+    __shared__ uint32_t s_count, s_wave[2], s_nsets, s_nt, s_npend, s_maxlevel, s_root;
+    const uint32_t t = threadIdx.x, li = blockIdx.x;
+    if (li >= n_leaves) return;
+    const uint32_t first = leaf_desc[li].x, pc = leaf_desc[li].y;   // pc <= kChunkDeviceLeafMax (the host checked)
+    // ---- the leaf's valid slots, in slot order (guards shader.wgsl:331, :336): rank = first rank + position here
+    if (t == 0) s_count = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < pc; base += kChunkDevBlock) {
+        const uint32_t i = base + t, slot = first + i;
+        const bool v = i < pc && slot < index_len && slot >= first && indices[slot] < tri_count;
+        const unsigned long long b = __ballot(v);
+        if ((t & 63u) == 0u) s_wave[t >> 6] = static_cast<uint32_t>(__popcll(b));
+        __syncthreads();
+        const uint32_t at = s_count + ((t >> 6) ? s_wave[0] : 0u) + static_cast<uint32_t>(__popcll(b & ((1ull << (t & 63u)) - 1ull)));
+        if (v) slots[at] = slot;
+        __syncthreads();
+        if (t == 0) s_count += s_wave[0] + s_wave[1];
+        __syncthreads();
+    }
+    const uint32_t count = s_count;
+    if (count == 0u) {
+        if (t == 0) {
+            if (COUNT) {
+                leaf_valid[li] = 0u;
+                leaf_nodes[li] = 0u;
+            } else {
+                leaf_info[li] = ChunkInfo();   // ref = kChunkNone: nothing to hit below
+            }
+        }
+        return;
+    }
+    const uint32_t r0 = COUNT ? 0u : rank0[li];
+    for (uint32_t j = t; j < count; j += kChunkDevBlock) {
+        chunkmath::make_item(tris[indices[slots[j]]], slots[j], r0 + j, items[j]);
+        if (!COUNT) rank_slot[r0 + j] = slots[j];
+    }
+    uint32_t n2 = 2;
+    while (n2 < count) n2 <<= 1;
+    __syncthreads();
+    // ---- ascending by the determinant-floor bound: the split-off sets are ranges of this order
+    for (uint32_t j = t; j < n2; j += kChunkDevBlock) {
+        key[j] = j < count ? static_cast<unsigned long long>(__double_as_longlong(items[j].cap)) : ~0ull;
+        perm[j] = j;
+    }
+    chunk_bitonic(key, perm, n2, t);
+    if (t == 0) {
+        uint32_t ns = 0, lo = 0;
+        const uint32_t hi = count;
+        while (hi - lo >= 2u && ns + 1u < kChunkDevSets) {
+            const double thr = 8.0 * items[perm[lo + (hi - lo) / 2u]].cap;   // 8 x the median (rb_bvh.cpp build_leaf)
+            uint32_t mid = lo;
+            while (mid < hi && items[perm[mid]].cap <= thr) ++mid;
+            if (!(mid > lo && mid < hi)) break;
+            set_lo[ns] = static_cast<uint16_t>(lo);
+            set_hi[ns] = static_cast<uint16_t>(mid);
+            ++ns;
+            lo = mid;
+        }
+        set_lo[ns] = static_cast<uint16_t>(lo);
+        set_hi[ns] = static_cast<uint16_t>(hi);
+        s_nsets = ns + 1u;
+    }
+    __syncthreads();
+    const uint32_t nsets = s_nsets;
+    if (COUNT) {
+        if (t == 0) {
+            uint32_t chunks = 0;
+            for (uint32_t s = 0; s < nsets; ++s) chunks += (set_hi[s] - set_lo[s] + kChunkTris - 1u) / kChunkTris;
+            leaf_valid[li] = count;
+            leaf_nodes[li] = chunks - 1u;
+        }
+        return;
+    }
+    // ---- the skeleton: a chain of joins over the sets (small bounds first), every set an unsplit entry
+    if (t == 0) {
+        uint32_t nt = 0, n_inner = 0, npend = 0, maxlevel = 0;
+        auto entry = [&](uint32_t lo, uint32_t hi, uint32_t k, uint32_t level, bool chain) {
+            ChunkDevT e;
+            e.lo = static_cast<uint16_t>(lo);
+            e.hi = static_cast<uint16_t>(hi);
+            e.k = static_cast<uint16_t>(k);
+            e.left = e.right = -1;
+            e.level = static_cast<uint16_t>(level);
+            e.inner = (chain || k > 1u) ? 1u : 0u;
+            e.ord = e.inner ? static_cast<uint16_t>(n_inner++) : 0u;
+            if (level > maxlevel) maxlevel = level;
+            tn[nt] = e;
+            if (!chain && k > 1u) pend[npend++] = static_cast<uint16_t>(nt);
+            return nt++;
+        };
+        auto chunks_of = [&](uint32_t s) { return (set_hi[s] - set_lo[s] + kChunkTris - 1u) / kChunkTris; };
+        if (nsets == 1u) {
+            entry(set_lo[0], set_hi[0], chunks_of(0), 0u, false);
+        } else {
+            uint32_t cur = entry(0u, count, 0u, 0u, true);
+            for (uint32_t s = 0; s + 1u < nsets; ++s) {
+                const uint32_t lv = tn[cur].level + 1u;
+                const uint32_t l = entry(set_lo[s], set_hi[s], chunks_of(s), lv, false);
+                const uint32_t r = (s + 2u < nsets) ? entry(set_lo[s + 1u], count, 0u, lv, true) : entry(set_lo[s + 1u], set_hi[s + 1u], chunks_of(s + 1u), lv, false);
+                tn[cur].left = static_cast<int16_t>(l);
+                tn[cur].right = static_cast<int16_t>(r);
+                cur = r;
+            }
+        }
+        s_root = 0u;
+        s_nt = nt;
+        s_npend = npend;
+        s_maxlevel = maxlevel;
+        // (n_inner continues below through tn[].ord of the entries the splits make; kept in s_wave[0])
+        s_wave[0] = n_inner;
+    }
+    __syncthreads();
+    // ---- median splits, a level of every unsplit entry at a time: longest axis of the centroids' extent, the items of the
+    // entry sorted along it (one sort of the whole leaf, keyed by the entry's first position so that nothing leaves its range)
+    while (s_npend > 0u) {
+        const uint32_t npend = s_npend;
+        for (uint32_t j = t; j < count; j += kChunkDevBlock) segof[j] = 0xFFu;
+        __syncthreads();
+        if (t < npend) {
+            const ChunkDevT e = tn[pend[t]];
+            float cmn[3] = {chunkmath::f_inf(), chunkmath::f_inf(), chunkmath::f_inf()}, cmx[3] = {-chunkmath::f_inf(), -chunkmath::f_inf(), -chunkmath::f_inf()};
+            for (uint32_t j = e.lo; j < e.hi; ++j) {
+                const ChunkItem& it = items[perm[j]];
+                for (int a = 0; a < 3; ++a) {
+                    const float c = 0.5f * (it.mn[a] + it.mx[a]);
+                    cmn[a] = c < cmn[a] ? c : cmn[a];
+                    cmx[a] = c > cmx[a] ? c : cmx[a];
+                }
+                segof[j] = static_cast<uint8_t>(t);
+            }
+            const float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
+            pend_axis[t] = (ex > ey && ex > ez) ? 0u : ((ey > ez) ? 1u : 2u);
+        }
+        __syncthreads();
+        for (uint32_t j = t; j < n2; j += kChunkDevBlock) {
+            unsigned long long k = ~0ull;
+            if (j < count) {
+                const uint32_t sg = segof[j];
+                if (sg == 0xFFu) {
+                    k = static_cast<unsigned long long>(j) << 32;
+                } else {
+                    const ChunkItem& it = items[perm[j]];
+                    const uint32_t a = pend_axis[sg];
+                    k = (static_cast<unsigned long long>(tn[pend[sg]].lo) << 32) | f2ord(0.5f * (it.mn[a] + it.mx[a]));
+                }
+            }
+            key[j] = k;
+        }
+        chunk_bitonic(key, perm, n2, t);
+        if (t == 0) {
+            uint32_t nt = s_nt, n_inner = s_wave[0], nnext = 0, maxlevel = s_maxlevel;
+            for (uint32_t i = 0; i < npend; ++i) {
+                const uint32_t p = pend[i];
+                const uint32_t lo = tn[p].lo, hi = tn[p].hi, k = tn[p].k, cnt = hi - lo, kl = k / 2u;
+                uint32_t take = cnt * kl / k;   // the left half gets floor(k / 2) of the k chunks: sizes stay within one of count / k
+                if (take < 1u) take = 1u;
+                const uint32_t mid = lo + take, lv = tn[p].level + 1u;
+                const uint32_t kk[2] = {kl, k - kl}, a[2] = {lo, mid}, b[2] = {mid, hi};
+                for (int side = 0; side < 2; ++side) {
+                    ChunkDevT e;
+                    e.lo = static_cast<uint16_t>(a[side]);
+                    e.hi = static_cast<uint16_t>(b[side]);
+                    e.k = static_cast<uint16_t>(kk[side]);
+                    e.left = e.right = -1;
+                    e.level = static_cast<uint16_t>(lv);
+                    e.inner = kk[side] > 1u ? 1u : 0u;
+                    e.ord = e.inner ? static_cast<uint16_t>(n_inner++) : 0u;
+                    tn[nt] = e;
+                    if (e.inner) pend_next[nnext++] = static_cast<uint16_t>(nt);
+                    if (side == 0) tn[p].left = static_cast<int16_t>(nt);
+                    else tn[p].right = static_cast<int16_t>(nt);
+                    ++nt;
+                }
+                if (lv > maxlevel) maxlevel = lv;
+            }
+            for (uint32_t i = 0; i < nnext; ++i) pend[i] = pend_next[i];
+            s_nt = nt;
+            s_wave[0] = n_inner;
+            s_npend = nnext;
+            s_maxlevel = maxlevel;
+        }
+        __syncthreads();
+    }
+    // ---- the chunks: positions in the final order, tight box, margins, cone
+    const uint32_t nt = s_nt, p0 = r0, nd0 = node0[li];   // a leaf's first position = its first rank: every valid slot is in exactly one chunk
+    for (uint32_t j = t; j < count; j += kChunkDevBlock) {
+        pos_slot[p0 + j] = items[perm[j]].slot;
+        pos_rank[p0 + j] = items[perm[j]].rank;
+    }
+    for (uint32_t i = t; i < nt; i += kChunkDevBlock) {
+        const ChunkDevT e = tn[i];
+        if (e.inner) continue;
+        ChunkInfo r;
+        for (uint32_t j = e.lo; j < e.hi; ++j) {
+            const ChunkItem& it = items[perm[j]];
+            r.cap = chunkmath::dmax(r.cap, it.cap);
+            r.fa = chunkmath::dmax(r.fa, it.fa);
+            r.cap_l = chunkmath::dmax(r.cap_l, it.cap_l);
+            r.fa_l = chunkmath::dmax(r.fa_l, it.fa_l);
+            for (int a = 0; a < 3; ++a) {
+                r.mn[a] = it.mn[a] < r.mn[a] ? it.mn[a] : r.mn[a];
+                r.mx[a] = it.mx[a] > r.mx[a] ? it.mx[a] : r.mx[a];
+            }
+        }
+        const uint32_t lo = e.lo;
+        r.cone = chunkmath::cone_of([&](uint32_t q) -> const ChunkItem& { return items[perm[lo + q]]; }, static_cast<uint32_t>(e.hi - e.lo));
+        r.ref = kChunkLeaf | ((static_cast<uint32_t>(e.hi - e.lo) - 1u) << 26) | (p0 + lo);
+        info[i] = r;
+    }
+    __syncthreads();
+    // ---- the library's own nodes, deepest level first (children carry the library's boxes: no kChunkExact)
+    for (uint32_t lv = s_maxlevel + 1u; lv-- > 0u;) {
+        for (uint32_t i = t; i < nt; i += kChunkDevBlock) {
+            const ChunkDevT e = tn[i];
+            if (!e.inner || e.level != lv) continue;
+            const ChunkInfo l = info[e.left], r = info[e.right];
+            ChunkNode n;
+            chunkmath::fill_child(l, l.mn, l.mx, n.lmin, n.lref, n.lmax, n.lfac, n.lcone);
+            chunkmath::fill_child(r, r.mn, r.mx, n.rmin, n.rref, n.rmax, n.rfac, n.rcone);
+            nodes[nd0 + e.ord] = n;
+            ChunkInfo up;
+            chunkmath::combine(l, r, up);
+            up.ref = nd0 + e.ord;
+            info[i] = up;
+        }
+        __syncthreads();
+    }
+    if (t == 0) leaf_info[li] = info[s_root];
+}
+
+__global__ void k_chunk_totals(const uint32_t* leaf_valid, const uint32_t* leaf_nodes, const uint32_t* rank0, const uint32_t* node0,
+                               uint32_t n_leaves, uint32_t* totals) {
+    totals[0] = rank0[n_leaves - 1u] + leaf_valid[n_leaves - 1u];
+    totals[1] = node0[n_leaves - 1u] + leaf_nodes[n_leaves - 1u];
+}
+}  // namespace
+
+int device_chunk_tree_build(const rb_gpu_triangle* d_tris, uint32_t tri_count, const uint32_t* d_indices, uint32_t index_len,
+                            const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, DeviceChunkTree* out, void* stream_) {
+    using chunkmath::ChunkInfo;
+    *out = DeviceChunkTree{};
+    if (node_count < 2u || index_len == 0u || tri_count == 0u || ref_nodes[0].primitive_count > 0u) return -1;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    std::vector<uint32_t> order, leaves;
+    if (!chunk_visit_order(ref_nodes, node_count, order, leaves) || leaves.empty() || leaves.size() >= (1u << 30)) return -1;
+    const uint32_t n_leaves = static_cast<uint32_t>(leaves.size());
+    std::vector<uint2> desc(n_leaves);
+    for (uint32_t i = 0; i < n_leaves; ++i) {
+        const rb_bvh_node& n = ref_nodes[leaves[i]];
+        if (n.primitive_count > kChunkDeviceLeafMax) return -1;   // a caller's tree with fatter leaves than the block holds: host builder
+        desc[i] = make_uint2(n.first_primitive, n.primitive_count);
+    }
+    size_t scan_bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, n_leaves,
+                                           rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    const size_t o_desc = carve(8u * size_t(n_leaves)), o_valid = carve(4u * size_t(n_leaves)), o_nodes = carve(4u * size_t(n_leaves));
+    const size_t o_rank0 = carve(4u * size_t(n_leaves)), o_node0 = carve(4u * size_t(n_leaves)), o_info = carve(sizeof(ChunkInfo) * size_t(n_leaves));
+    const size_t o_tot = carve(8), o_scan = carve(scan_bytes);
+    char* base = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&base), off);
+    if (e != hipSuccess) return static_cast<int>(e);
+    ChunkNode* d_nodes = nullptr;
+    uint32_t *d_pos_slot = nullptr, *d_pos_rank = nullptr, *d_rank_slot = nullptr;
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(base);
+        if (d_nodes) (void)hipFree(d_nodes);
+        if (d_pos_slot) (void)hipFree(d_pos_slot);
+        if (d_pos_rank) (void)hipFree(d_pos_rank);
+        if (d_rank_slot) (void)hipFree(d_rank_slot);
+        return code;
+    };
+    auto at = [&](size_t o) { return base + o; };
+    uint2* d_desc = reinterpret_cast<uint2*>(at(o_desc));
+    uint32_t *d_valid = reinterpret_cast<uint32_t*>(at(o_valid)), *d_lnodes = reinterpret_cast<uint32_t*>(at(o_nodes));
+    uint32_t *d_rank0 = reinterpret_cast<uint32_t*>(at(o_rank0)), *d_node0 = reinterpret_cast<uint32_t*>(at(o_node0));
+    ChunkInfo* d_info = reinterpret_cast<ChunkInfo*>(at(o_info));
+    uint32_t* d_tot = reinterpret_cast<uint32_t*>(at(o_tot));
+    e = hipMemcpyAsync(d_desc, desc.data(), 8u * size_t(n_leaves), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    hipLaunchKernelGGL(k_chunk_leaves<true>, dim3(n_leaves), dim3(kChunkDevBlock), 0, stream, d_tris, tri_count, d_indices, index_len, d_desc, n_leaves,
+                       d_valid, d_lnodes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    e = rocprim::exclusive_scan(at(o_scan), scan_bytes, d_valid, d_rank0, 0u, n_leaves, rocprim::plus<uint32_t>(), stream);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(at(o_scan), scan_bytes, d_lnodes, d_node0, 0u, n_leaves, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1), 0, stream, d_valid, d_lnodes, d_rank0, d_node0, n_leaves, d_tot);
+    uint32_t tot[2] = {0, 0};
+    e = hipMemcpyAsync(tot, d_tot, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    const uint32_t rank = tot[0], n_dev_nodes = tot[1];
+    // (the scans are 32-bit sums of at most index_len <= 2^31 slots; the limits below are the reference formats': rank in 26 bits)
+    if (rank == 0u || rank >= (1u << 26) - 64u) return fail(-1);
+    const size_t n_top_max = order.size() - leaves.size();
+    if (size_t(n_dev_nodes) + n_top_max >= (1u << 30)) return fail(-1);
+    e = hipMalloc(reinterpret_cast<void**>(&d_nodes), sizeof(ChunkNode) * (size_t(n_dev_nodes) + n_top_max));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_pos_slot), 4u * size_t(rank));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_pos_rank), 4u * size_t(rank));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rank_slot), 4u * size_t(rank));
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    hipLaunchKernelGGL(k_chunk_leaves<false>, dim3(n_leaves), dim3(kChunkDevBlock), 0, stream, d_tris, tri_count, d_indices, index_len, d_desc, n_leaves,
+                       nullptr, nullptr, d_rank0, d_node0, d_nodes, d_pos_slot, d_pos_rank, d_rank_slot, d_info);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    std::vector<ChunkInfo> leaf_info(n_leaves), info(node_count);
+    e = hipMemcpyAsync(leaf_info.data(), d_info, sizeof(ChunkInfo) * size_t(n_leaves), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(static_cast<int>(e));
+    for (uint32_t i = 0; i < n_leaves; ++i) info[leaves[i]] = leaf_info[i];
+    std::vector<ChunkNode> top;
+    top.reserve(n_top_max);
+    chunk_top_pass(ref_nodes, node_count, order, info, top, n_dev_nodes);
+    const uint32_t root = info[0].ref, depth = info[0].depth;
+    if (root == kChunkNone || depth + 1u > stack_limit) return fail(-1);
+    if (!top.empty()) {
+        e = hipMemcpyAsync(d_nodes + n_dev_nodes, top.data(), sizeof(ChunkNode) * top.size(), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `top` is a local
+        if (e != hipSuccess) return fail(static_cast<int>(e));
+    }
+    (void)hipFree(base);
+    out->nodes = d_nodes;
+    out->n_nodes = size_t(n_dev_nodes) + top.size();
+    out->nodes_capacity = size_t(n_dev_nodes) + n_top_max;
+    out->pos_slot = d_pos_slot;
+    out->pos_rank = d_pos_rank;
+    out->rank_slot = d_rank_slot;
+    out->n_pos = rank;
+    out->root = root;
+    out->depth = depth;
+    return 0;
 }
 
 // All work is queued on `stream`; `info_out` (host) is valid when this returns (it synchronises).

@@ -11,6 +11,7 @@
 //   malformed tree (cycle, out-of-range child, depth beyond the kernel stack) is
 //   rejected on the host before it can hang the GPU.
 #include "rb_internal.hpp"
+#include "rb_chunk_math.hpp"
 
 #include <algorithm>
 #include <array>
@@ -477,55 +478,10 @@ struct FBuilder {
 
 // F_k of one triangle and whether it is "large" (see the comment above FBuilder), from the f32 edges the kernels
 // use.  The device builder gets the flag from slot_meta and repeats the arithmetic in double (rb_build.hip).
-TriBound tri_bound(const rb_gpu_triangle& t, float small_cap) {
-    double e1[3], e2[3], l1 = 0, l2 = 0;
-    for (int a = 0; a < 3; ++a) {
-        e1[a] = double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
-        e2[a] = double(t.v2[a] - t.v0[a]);
-        l1 += e1[a] * e1[a];
-        l2 += e2[a] * e2[a];
-    }
-    TriBound b;
-    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz), ll = std::max(l1, l2);
-    const double cap = ll * 1e6 * (1.0 + 1e-5);   // L^2 / fl(1e-6), rounded up
-    b.has_normal = nn > 0.0 && std::isfinite(nn);
-    if (b.has_normal) {
-        b.n[0] = nx / nn; b.n[1] = ny / nn; b.n[2] = nz / nn;
-    }
-    b.large = !(cap <= double(small_cap));
-    if (!b.large) b.f = static_cast<float>(cap * (1.0 + 1e-6));
-    else if (b.has_normal) b.f = static_cast<float>(ll / nn / (0.95 * double(kFastGrazeCos)) * (1.0 + 1e-5));   // 0.95: |a^| >= 0.95 |a| in the bound's range
-    else b.f = std::numeric_limits<float>::infinity();
-    return b;
-}
+TriBound tri_bound(const rb_gpu_triangle& t, float small_cap) { return chunkmath::tri_bound_hd(t.v0, t.v1, t.v2, small_cap); }
 
-namespace {
-// cone of unit normals: axis c, half-angle alpha; `valid` false = "no useful cone" (wider than ~89 degrees)
-struct DCone {
-    double c[3] = {0, 0, 0}, alpha = 4.0;
-    bool valid = false;
-    double cap = 0.0;   // largest L^2 / 1e-6 over the large triangles below
-};
-DCone merge(const DCone& a, const DCone& b_) {
-    DCone out;
-    out.cap = std::max(a.cap, b_.cap);
-    if (!a.valid || !b_.valid) return out;
-    DCone b = b_;
-    if (a.c[0] * b.c[0] + a.c[1] * b.c[1] + a.c[2] * b.c[2] < 0.0)
-        for (double& x : b.c) x = -x;
-    double s[3] = {a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]};
-    const double len = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
-    if (!(len > 1e-9)) return out;
-    for (double& x : s) x /= len;
-    auto ang = [&](const double v[3]) { return std::acos(std::min(1.0, std::max(-1.0, s[0] * v[0] + s[1] * v[1] + s[2] * v[2]))); };
-    out.alpha = std::max(ang(a.c) + a.alpha, ang(b.c) + b.alpha) + 1e-9;
-    if (!(out.alpha < 1.55)) { DCone bad; bad.cap = out.cap; return bad; }
-    for (int i = 0; i < 3; ++i) out.c[i] = s[i];
-    out.valid = true;
-    return out;
-}
-}  // namespace
+using chunkmath::DCone;   // cone of unit normals (rb_chunk_math.hpp: shared with the device builder)
+using chunkmath::merge;
 
 bool fast_bvh_prepare(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                       const rb_bvh_node* ref_nodes, uint32_t node_count, FastTree& out, float small_cap) {
@@ -724,102 +680,17 @@ bool fast_bvh_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint3
 // the walk which of the two a given ray needs.  Triangles are renumbered chunk by chunk; the reference's visit order
 // survives as the rank that breaks ties in t.
 namespace {
-struct ChunkInfo {
-    uint32_t ref = kChunkNone;
-    double cap = 0.0, fa = 0.0;      // with G = max(|e1| |e2|, L^2 / 4) (chunk_g)
-    double cap_l = 0.0, fa_l = 0.0;  // with L^2: what is stored where a triangle below is beyond the range the bounds are claimed for
-    DCone cone;
-    uint32_t depth = 0;   // internal nodes on the longest path below (= stack entries the walk may need)
-    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};   // tight bounds of the triangles below
-};
-struct ChunkItem {
-    uint32_t slot, rank;
-    float mn[3], mx[3];
-    double cap, fa, cap_l, fa_l;
-    double n[3];
-    bool has_normal;
-};
-DCone empty_cone() {
-    DCone c;
-    c.valid = true;
-    c.alpha = -1.0;
-    c.c[0] = 1.0;
-    return c;
-}
-DCone merge_cones(const DCone& a, const DCone& b) {
-    if (a.valid && a.alpha < 0.0) return b;
-    if (b.valid && b.alpha < 0.0) return a;
-    return merge(a, b);
-}
-// direct cone of a handful of normals (either orientation): axis = normalised sum of the sign-aligned normals
-DCone cone_of(const ChunkItem* it, size_t n) {
-    DCone c;
-    if (n == 0) return empty_cone();
-    double sum[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; ++i) {
-        if (!it[i].has_normal) return c;   // no normal: any direction grazes it
-        const double sg = (it[i].n[0] * it[0].n[0] + it[i].n[1] * it[0].n[1] + it[i].n[2] * it[0].n[2]) < 0.0 ? -1.0 : 1.0;
-        for (int a = 0; a < 3; ++a) sum[a] += sg * it[i].n[a];
-    }
-    const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-    if (!(len > 1e-9)) return c;
-    double cmin = 1.0;
-    for (int a = 0; a < 3; ++a) c.c[a] = sum[a] / len;
-    for (size_t i = 0; i < n; ++i) cmin = std::min(cmin, std::fabs(it[i].n[0] * c.c[0] + it[i].n[1] * c.c[1] + it[i].n[2] * c.c[2]));
-    c.alpha = std::acos(std::min(1.0, cmin)) + 1e-9;
-    c.valid = c.alpha < 1.55;
-    return c;
-}
-// {axis cos(alpha), tan(alpha)} as FastWalk::graze_possible reads it; all zeros = "any ray may graze a triangle below"
-void encode_cone(const DCone& c, float o[4]) {
-    o[0] = o[1] = o[2] = o[3] = 0.0f;
-    if (!c.valid) return;
-    if (c.alpha < 0.0) { o[3] = -1.0f; return; }   // nothing below
-    const double cos_a = std::cos(c.alpha) * (1.0 - 1e-6) - 1e-7;
-    if (!(cos_a > 0.0175)) return;
-    const double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
-    o[0] = static_cast<float>(c.c[0] * cos_a);
-    o[1] = static_cast<float>(c.c[1] * cos_a);
-    o[2] = static_cast<float>(c.c[2] * cos_a);
-    o[3] = static_cast<float>(sin_a / cos_a * (1.0 + 1e-5) + 1e-7);
-}
-// E7's leading terms carry |e1| |e2| where r02 wrote L^2 = max(|e1|, |e2|)^2: the chunked walk stores its bounds with
-// G = |e1| |e2| in place of L^2.  The bounds are claimed while 5.42 u L^2 / |a^| <= 0.05 -- with L^2.  An accepted hit has
-// |a^| >= 1e-6, so that holds for every triangle with L^2 / 1e-6 <= 1.5e5 whatever the ray; a child slot with a larger
-// triangle below it stores +inf as its floor bound and its |cos| >= c0 bound with L^2, as r02 did, so that the kernel's test
-// "F <= 1.5e5" is the proviso itself there (pack_fac).
-double chunk_g(double l1sq, double l2sq) { return std::sqrt(l1sq) * std::sqrt(l2sq) * (1.0 + 1e-12); }
-// v >= 0 as bf16, rounded up; beyond 1.5e5 (where the bound is not claimed) +inf
-uint32_t bf16_up(double v) {
-    if (!(v <= 1.5e5)) return 0x7F80u;
-    float f = static_cast<float>(v);
-    if (static_cast<double>(f) < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
-    uint32_t b;
-    std::memcpy(&b, &f, 4);
-    return (b >> 16) + ((b & 0xFFFFu) ? 1u : 0u);
-}
-uint32_t pack_fac(const ChunkInfo& i) {
-    if (!(i.cap_l * (1.0 + 1e-6) <= 1.5e5)) return (0x7F80u << 16) | bf16_up(i.fa_l);
-    return (bf16_up(i.cap * (1.0 + 1e-6)) << 16) | bf16_up(i.fa);
-}
+// the per-triangle and per-subtree arithmetic lives in rb_chunk_math.hpp (host + device)
+using chunkmath::ChunkInfo;
+using chunkmath::ChunkItem;
+using chunkmath::chunk_g;
+using chunkmath::empty_cone;
+using chunkmath::merge_cones;
 
 struct ChunkBuilder {
     ChunkTree& out;
     std::vector<ChunkItem>& items;
 
-    void fill_child(const ChunkInfo& i, const float mn[3], const float mx[3], float bmin[3], uint32_t& ref, float bmax[3],
-                    uint32_t& fac, float cone[4]) const {
-        std::memcpy(bmin, mn, 12);
-        std::memcpy(bmax, mx, 12);
-        ref = i.ref;
-        fac = pack_fac(i);
-        // the margins bound the distance of a reported hit from its TRIANGLE; culling on a box needs the triangles
-        // inside it.  The reference's builder guarantees that (bvh.rs:100-123), a caller's own tree need not: such a
-        // child is always entered (its reference box still decides, exactly, whether the leaf below is reached)
-        for (int a = 0; a < 3; ++a)
-            if (i.ref != kChunkNone && !(mn[a] <= i.mn[a] && i.mx[a] <= mx[a])) fac = 0x7F807F80u;
-        encode_cone(i.cone, cone);
-    }
     void tight(size_t lo, size_t hi, float mn[3], float mx[3]) const {
         for (int a = 0; a < 3; ++a) { mn[a] = kInf; mx[a] = -kInf; }
         for (size_t i = lo; i < hi; ++i)
@@ -843,7 +714,7 @@ struct ChunkBuilder {
                 r.fa_l = std::max(r.fa_l, items[i].fa_l);
             }
             tight(lo, hi, r.mn, r.mx);
-            r.cone = cone_of(&items[lo], count);
+            r.cone = chunkmath::cone_of([&](uint32_t i) -> const ChunkItem& { return items[lo + i]; }, static_cast<uint32_t>(count));
             r.ref = kChunkLeaf | (static_cast<uint32_t>(count - 1) << 26) | first;
             return r;
         }
@@ -869,17 +740,12 @@ struct ChunkBuilder {
         ChunkNode n{};
         float mn[3], mx[3];
         tight(lo, mid, mn, mx);
-        fill_child(l, mn, mx, n.lmin, n.lref, n.lmax, n.lfac, n.lcone);
+        chunkmath::fill_child(l, mn, mx, n.lmin, n.lref, n.lmax, n.lfac, n.lcone);
         tight(mid, hi, mn, mx);
-        fill_child(rr, mn, mx, n.rmin, n.rref, n.rmax, n.rfac, n.rcone);
+        chunkmath::fill_child(rr, mn, mx, n.rmin, n.rref, n.rmax, n.rfac, n.rcone);
         r.ref = static_cast<uint32_t>(out.nodes.size());   // children carry the library's own boxes: no kChunkExact
         out.nodes.push_back(n);
-        r.cap = std::max(l.cap, rr.cap);
-        r.fa = std::max(l.fa, rr.fa);
-        r.cap_l = std::max(l.cap_l, rr.cap_l);
-        r.fa_l = std::max(l.fa_l, rr.fa_l);
-        r.cone = merge_cones(l.cone, rr.cone);
-        r.depth = 1 + std::max(l.depth, rr.depth);
+        chunkmath::combine(l, rr, r);
         tight(lo, hi, r.mn, r.mx);
         return r;
     }
@@ -904,6 +770,54 @@ struct ChunkBuilder {
 };
 }  // namespace
 
+// The reference's visit order (right child first, shader.wgsl:376-387): nodes parents-first, leaves in visit order.
+bool chunk_visit_order(const rb_bvh_node* ref_nodes, uint32_t node_count, std::vector<uint32_t>& order, std::vector<uint32_t>& leaves) {
+    std::vector<uint32_t> st{0u};
+    order.clear();
+    leaves.clear();
+    while (!st.empty()) {
+        const uint32_t ni = st.back();
+        st.pop_back();
+        order.push_back(ni);
+        if (order.size() > node_count) return false;
+        const rb_bvh_node& n = ref_nodes[ni];
+        if (n.primitive_count > 0) {
+            leaves.push_back(ni);
+        } else {
+            if (n.left < node_count) st.push_back(n.left);
+            if (n.right < node_count) st.push_back(n.right);
+        }
+    }
+    return true;
+}
+
+// Bottom-up over the caller's internal nodes, children before parents: `info` holds what the subtrees below the reference
+// leaves handed up; the nodes made here carry the REFERENCE boxes (kChunkExact) and are appended to `nodes`, whose first
+// element has index `first_index` in the tree's node array.
+void chunk_top_pass(const rb_bvh_node* ref_nodes, uint32_t node_count, const std::vector<uint32_t>& order, std::vector<ChunkInfo>& info,
+                    std::vector<ChunkNode>& nodes, uint32_t first_index) {
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t ni = order[k];
+        const rb_bvh_node& n = ref_nodes[ni];
+        ChunkInfo& r = info[ni];
+        if (n.primitive_count > 0) continue;
+        const bool hl = n.left < node_count, hr = n.right < node_count;
+        const ChunkInfo none;
+        const ChunkInfo& l = hl ? info[n.left] : none;
+        const ChunkInfo& rr = hr ? info[n.right] : none;
+        if (l.ref == kChunkNone && rr.ref == kChunkNone) continue;   // nothing to hit below
+        ChunkNode c{};
+        const float zero[3] = {0, 0, 0};
+        chunkmath::fill_child(l, hl ? ref_nodes[n.left].aabb_min : zero, hl ? ref_nodes[n.left].aabb_max : zero, c.lmin, c.lref, c.lmax,
+                              c.lfac, c.lcone);
+        chunkmath::fill_child(rr, hr ? ref_nodes[n.right].aabb_min : zero, hr ? ref_nodes[n.right].aabb_max : zero, c.rmin, c.rref,
+                              c.rmax, c.rfac, c.rcone);
+        r.ref = (first_index + static_cast<uint32_t>(nodes.size())) | kChunkExact;
+        nodes.push_back(c);
+        chunkmath::combine(l, rr, r);
+    }
+}
+
 bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                       const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, ChunkTree& out) {
     out = ChunkTree{};
@@ -922,21 +836,8 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
         for (size_t t = 0; t < threads; ++t) pool.emplace_back(fn, std::min(t * per, n), std::min((t + 1) * per, n));
         for (std::thread& th : pool) th.join();
     };
-    // ---- the reference's visit order (right child first, shader.wgsl:376-387): nodes parents-first, leaves in visit order
-    std::vector<uint32_t> order, st{0u}, leaves;
-    while (!st.empty()) {
-        const uint32_t ni = st.back();
-        st.pop_back();
-        order.push_back(ni);
-        if (order.size() > node_count) return false;
-        const rb_bvh_node& n = ref_nodes[ni];
-        if (n.primitive_count > 0) {
-            leaves.push_back(ni);
-        } else {
-            if (n.left < node_count) st.push_back(n.left);
-            if (n.right < node_count) st.push_back(n.right);
-        }
-    }
+    std::vector<uint32_t> order, leaves;
+    if (!chunk_visit_order(ref_nodes, node_count, order, leaves)) return false;
     // ranks: a leaf's first rank = the valid slots (guards :331, :336) of the leaves visited before it
     auto valid = [&](uint32_t slot) { return slot < index_len && indices[slot] < tri_count; };
     std::vector<uint32_t> leaf_rank0(leaves.size() + 1, 0u);
@@ -973,26 +874,9 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             for (uint32_t i = 0; i < n.primitive_count; ++i) {
                 const uint32_t slot = n.first_primitive + i;
                 if (!valid(slot)) continue;
-                const rb_gpu_triangle& t = tris[indices[slot]];
                 ChunkItem it;
-                it.slot = slot;
                 out.rank_slot[rk] = slot;
-                it.rank = rk++;
-                double ll = 0, l2 = 0;
-                for (int a = 0; a < 3; ++a) {
-                    it.mn[a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
-                    it.mx[a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
-                    ll += double(t.v1[a] - t.v0[a]) * double(t.v1[a] - t.v0[a]);   // the f32 edges of k_prep_tris, exactly
-                    l2 += double(t.v2[a] - t.v0[a]) * double(t.v2[a] - t.v0[a]);
-                }
-                const TriBound b = tri_bound(t, 0.0f);   // threshold 0: every triangle keeps its |cos| >= c0 bound (of L^2 / |a|)
-                const double g = chunk_g(ll, l2), lmax = std::max(ll, l2);
-                it.cap = g * 1e6 * (1.0 + 1e-5);
-                it.fa = (b.has_normal && lmax > 0.0) ? double(b.f) * (g / lmax) * (1.0 + 1e-9) : double(b.f);   // no normal: +inf; a point: 0
-                it.cap_l = lmax * 1e6 * (1.0 + 1e-5);
-                it.fa_l = b.f;
-                it.has_normal = b.has_normal;
-                for (int a = 0; a < 3; ++a) it.n[a] = b.n[a];
+                chunkmath::make_item(tris[indices[slot]], slot, rk++, it);
                 items.push_back(it);
             }
             if (items.empty()) continue;
@@ -1034,41 +918,7 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
             }
         });
     }
-    // ---- bottom-up over the caller's internal nodes: children before parents
-    for (size_t k = order.size(); k-- > 0;) {
-        const uint32_t ni = order[k];
-        const rb_bvh_node& n = ref_nodes[ni];
-        ChunkInfo& r = info[ni];
-        if (n.primitive_count > 0) continue;
-        {
-            const bool hl = n.left < node_count, hr = n.right < node_count;
-            const ChunkInfo none;
-            const ChunkInfo& l = hl ? info[n.left] : none;
-            const ChunkInfo& rr = hr ? info[n.right] : none;
-            if (l.ref == kChunkNone && rr.ref == kChunkNone) continue;   // nothing to hit below
-            ChunkNode c{};
-            const float zero[3] = {0, 0, 0};
-            std::vector<ChunkItem> no_items;
-            ChunkTree no_tree;
-            ChunkBuilder cb{no_tree, no_items};
-            cb.fill_child(l, hl ? ref_nodes[n.left].aabb_min : zero, hl ? ref_nodes[n.left].aabb_max : zero, c.lmin, c.lref, c.lmax,
-                          c.lfac, c.lcone);
-            cb.fill_child(rr, hr ? ref_nodes[n.right].aabb_min : zero, hr ? ref_nodes[n.right].aabb_max : zero, c.rmin, c.rref,
-                          c.rmax, c.rfac, c.rcone);
-            r.ref = static_cast<uint32_t>(out.nodes.size()) | kChunkExact;
-            out.nodes.push_back(c);
-            r.cap = std::max(l.cap, rr.cap);
-            r.fa = std::max(l.fa, rr.fa);
-            r.cap_l = std::max(l.cap_l, rr.cap_l);
-            r.fa_l = std::max(l.fa_l, rr.fa_l);
-            r.cone = merge_cones(l.ref == kChunkNone ? empty_cone() : l.cone, rr.ref == kChunkNone ? empty_cone() : rr.cone);
-            r.depth = 1 + std::max(l.depth, rr.depth);
-            for (int a = 0; a < 3; ++a) {
-                r.mn[a] = std::min(l.mn[a], rr.mn[a]);
-                r.mx[a] = std::max(l.mx[a], rr.mx[a]);
-            }
-        }
-    }
+    chunk_top_pass(ref_nodes, node_count, order, info, out.nodes, 0u);
     out.root = info[0].ref;
     out.depth = info[0].depth;
     if (out.root == kChunkNone || out.nodes.size() >= (1u << 30)) return false;

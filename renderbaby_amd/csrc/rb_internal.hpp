@@ -203,6 +203,22 @@ bool chunk_tree_build(const rb_gpu_triangle* tris, uint32_t tri_count, const uin
 bool chunk_tree_check(const ChunkTree& t, const rb_gpu_triangle* tris, uint32_t tri_count, const uint32_t* indices, uint32_t index_len,
                       uint32_t stack_limit, std::string& why);   // the structural invariants k_trace_chunk relies on
 
+// ---- rb_build.hip: the chunked walk's tree built on the device: one thread block per reference leaf for the library's own
+// levels, the caller's internal nodes by the host's bottom-up pass.  Returns 0 (built: the device arrays are the caller's
+// to hipFree), -1 (not for this builder: a leaf beyond kChunkDeviceLeafMax triangles, or a tree the chunked walk does not
+// take at all -- the host builder decides), or a hipError_t.
+constexpr uint32_t kChunkDeviceLeafMax = 256;       // bvh.rs:12 MAX_LEAF_SIZE = 128
+constexpr uint32_t kChunkDeviceBuildMin = 16384;    // slots from which the device builder is the default (below, the host's is microseconds)
+struct DeviceChunkTree {
+    ChunkNode* nodes = nullptr;
+    size_t n_nodes = 0, nodes_capacity = 0;
+    uint32_t *pos_slot = nullptr, *pos_rank = nullptr, *rank_slot = nullptr;
+    size_t n_pos = 0;
+    uint32_t root = kChunkNone, depth = 0;
+};
+int device_chunk_tree_build(const rb_gpu_triangle* d_tris, uint32_t tri_count, const uint32_t* d_indices, uint32_t index_len,
+                            const rb_bvh_node* ref_nodes, uint32_t node_count, uint32_t stack_limit, DeviceChunkTree* out, void* stream);
+
 // ---- rb_build.hip: the same tree built on the device (RB_FLAG_DEVICE_BVH), Morton order + LBVH
 struct DeviceTreeInfo {
     uint32_t root, depth;

@@ -56,6 +56,11 @@ struct DevBuf {
         if (e == hipSuccess) count = n;
         return e;
     }
+    void adopt(T* p, size_t n) {   // take over an allocation made elsewhere (rb_build.hip)
+        release();
+        ptr = p;
+        count = n;
+    }
     // scratch that is sized per launch: keep an allocation that is large enough and not wastefully so
     hipError_t reserve(size_t n) {
         if (ptr && n <= count && count <= 4 * std::max<size_t>(n, 1)) return hipSuccess;
@@ -134,6 +139,9 @@ struct rb_engine {
     DevBuf<rb::ChunkNode> chunk_nodes; // the chunked walk (rb_internal.hpp, ChunkTree)
     DevBuf<float> chunk_a, chunk_b, chunk_c;
     DevBuf<uint32_t> chunk_rank_slot;
+    DevBuf<uint32_t> chunk_pos_slot, chunk_pos_rank;   // chunk order -> slot / rank: read by the gather at build time, kept for rb_debug_engine_chunk_tree
+    size_t chunk_n_nodes = 0;
+    const char* chunk_builder = "";   // "device" | "host"
     uint32_t chunk_root = 0, chunk_depth = 0;
     bool chunk_ready = false;
     float chunk_build_ms = 0.0f;
@@ -585,27 +593,57 @@ int ensure_prepared(rb_engine* e) {
     e->chunk_ready = false;
     e->fast_ready = false;
     if (wants_chunk_walk(e) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
-        rb::ChunkTree ct;
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
-        if (rb::chunk_tree_build(e->host_tris.data(), n_tris, e->host_indices.data(), static_cast<uint32_t>(e->host_indices.size()),
-                                 e->host_nodes.data(), static_cast<uint32_t>(e->host_nodes.size()), rb::kStackDepth, ct)) {
-            const size_t n = ct.pos_slot.size();
-            DevBuf<uint32_t> pos_slot, pos_rank;
-            rc = upload(e, e->chunk_nodes, ct.nodes.data(), ct.nodes.size(), nullptr, true);
-            if (!rc) rc = upload(e, e->chunk_rank_slot, ct.rank_slot.data(), ct.rank_slot.size(), nullptr, true);
-            if (!rc) rc = upload(e, pos_slot, ct.pos_slot.data(), n, nullptr, true);
-            if (!rc) rc = upload(e, pos_rank, ct.pos_rank.data(), n, nullptr, true);
-            if (rc) return rc;
+        const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size()), n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+        // which builder: the device one from kChunkDeviceBuildMin slots up (one block per reference leaf; C5's 10^6 triangles
+        // in a few ms where the host's threads take 11-15), the host's below; either can be forced.  Same walk, same frames.
+        const bool force_host = (e->opt.flags & RB_FLAG_CHUNK_TREE_HOST) != 0u, force_dev = (e->opt.flags & RB_FLAG_CHUNK_TREE_DEVICE) != 0u;
+        bool built = false;
+        size_t n = 0;
+        e->chunk_builder = "";
+        if (!force_host && (force_dev || n_idx >= rb::kChunkDeviceBuildMin) && n_idx <= e->indices.count && n_tris <= e->tris.count) {
+            rb::DeviceChunkTree dt;
+            const int brc = rb::device_chunk_tree_build(e->tris.ptr, n_tris, e->indices.ptr, n_idx, e->host_nodes.data(), n_nodes, rb::kStackDepth, &dt, e->stream);
+            if (brc > 0) return fail(e, RB_ERR_DEVICE, "chunk tree build failed: %s", hipGetErrorString(static_cast<hipError_t>(brc)));
+            if (brc == 0) {
+                e->chunk_nodes.adopt(dt.nodes, dt.nodes_capacity);
+                e->chunk_rank_slot.adopt(dt.rank_slot, dt.n_pos);
+                e->chunk_pos_slot.adopt(dt.pos_slot, dt.n_pos);
+                e->chunk_pos_rank.adopt(dt.pos_rank, dt.n_pos);
+                e->chunk_n_nodes = dt.n_nodes;
+                e->chunk_root = dt.root;
+                e->chunk_depth = dt.depth;
+                n = dt.n_pos;
+                built = true;
+                e->chunk_builder = "device";
+            }
+        }
+        if (!built) {
+            rb::ChunkTree ct;
+            if (rb::chunk_tree_build(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, rb::kStackDepth, ct)) {
+                n = ct.pos_slot.size();
+                rc = upload(e, e->chunk_nodes, ct.nodes.data(), ct.nodes.size(), nullptr, true);
+                if (!rc) rc = upload(e, e->chunk_rank_slot, ct.rank_slot.data(), ct.rank_slot.size(), nullptr, true);
+                if (!rc) rc = upload(e, e->chunk_pos_slot, ct.pos_slot.data(), n, nullptr, true);
+                if (!rc) rc = upload(e, e->chunk_pos_rank, ct.pos_rank.data(), n, nullptr, true);
+                if (rc) return rc;
+                HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ct` is a local
+                e->chunk_n_nodes = ct.nodes.size();
+                e->chunk_root = ct.root;
+                e->chunk_depth = ct.depth;
+                built = true;
+                e->chunk_builder = "host";
+            }
+        }
+        if (built) {
             HIP_TRY(e, e->chunk_a.resize(n * 4));
             HIP_TRY(e, e->chunk_b.resize(n * 4));
             HIP_TRY(e, e->chunk_c.resize(n * 4));
-            rc = rb::launch_chunk_gather(e->ptris.ptr, pos_slot.ptr, pos_rank.ptr, static_cast<uint32_t>(n), e->chunk_a.ptr, e->chunk_b.ptr,
+            rc = rb::launch_chunk_gather(e->ptris.ptr, e->chunk_pos_slot.ptr, e->chunk_pos_rank.ptr, static_cast<uint32_t>(n), e->chunk_a.ptr, e->chunk_b.ptr,
                                          e->chunk_c.ptr, e->stream);
             if (rc) return fail(e, RB_ERR_DEVICE, "chunk gather launch failed");
-            HIP_TRY(e, hipStreamSynchronize(e->stream));  // `ct`, pos_slot and pos_rank are locals
-            e->chunk_root = ct.root;
-            e->chunk_depth = ct.depth;
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
             e->chunk_ready = true;
             e->chunk_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         }
@@ -1800,6 +1838,22 @@ int rb_debug_div_exhaustive(uint32_t b_begin, uint32_t b_count, uint32_t ea, uin
     return (rc || st != hipSuccess) ? RB_ERR_DEVICE : RB_OK;
 }
 
+namespace {
+void chunk_tree_census(const rb::ChunkTree& t, uint64_t out6[6]) {
+    uint64_t chunks = 0, unbounded = 0;
+    for (const rb::ChunkNode& c : t.nodes) {
+        chunks += ((c.lref != rb::kChunkNone && (c.lref & rb::kChunkLeaf)) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rref & rb::kChunkLeaf)) ? 1 : 0);
+        unbounded += ((c.lref != rb::kChunkNone && (c.lfac >> 16) == 0x7F80u) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rfac >> 16) == 0x7F80u) ? 1 : 0);
+    }
+    out6[0] = 1;
+    out6[1] = t.nodes.size();
+    out6[2] = t.pos_slot.size();
+    out6[3] = t.depth;
+    out6[4] = chunks;
+    out6[5] = unbounded;
+}
+}  // namespace
+
 // Test aid (host only): the chunked walk's tree for a mesh and a caller tree, with its invariants checked.
 int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh_node* nodes, size_t n_nodes, const uint32_t* indices,
                         size_t n_indices, uint64_t out6[6]) {
@@ -1814,18 +1868,42 @@ int rb_debug_chunk_tree(const rb_gpu_triangle* tris, size_t n_tris, const rb_bvh
         return RB_OK;   // out6[0] == 0: this tree is left to another walk
     if (!rb::chunk_tree_check(t, tris, static_cast<uint32_t>(n_tris), indices, static_cast<uint32_t>(n_indices), rb::kStackDepth, why))
         return fail(nullptr, RB_ERR_INVALID_BVH, "chunk tree: %s", why.c_str());
-    uint64_t chunks = 0, unbounded = 0;
-    for (const rb::ChunkNode& c : t.nodes) {
-        chunks += ((c.lref != rb::kChunkNone && (c.lref & rb::kChunkLeaf)) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rref & rb::kChunkLeaf)) ? 1 : 0);
-        unbounded += ((c.lref != rb::kChunkNone && (c.lfac >> 16) == 0x7F80u) ? 1 : 0) + ((c.rref != rb::kChunkNone && (c.rfac >> 16) == 0x7F80u) ? 1 : 0);
-    }
-    out6[0] = 1;
-    out6[1] = t.nodes.size();
-    out6[2] = t.pos_slot.size();
-    out6[3] = t.depth;
-    out6[4] = chunks;
-    out6[5] = unbounded;
+    chunk_tree_census(t, out6);
     return RB_OK;
+}
+
+int rb_debug_engine_chunk_tree(rb_engine* e, uint64_t out6[6]) {
+    if (!e || !out6) return RB_ERR_NULL_ARGUMENT;
+    if (is_group(e)) e = e->parts[0].get();
+    std::lock_guard<std::mutex> lock(e->mu);
+    set_device(e);
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (!e->chunk_ready) return RB_OK;
+    rb::ChunkTree t;
+    const size_t n = e->chunk_rank_slot.count;
+    t.nodes.resize(e->chunk_n_nodes);
+    t.pos_slot.resize(n);
+    t.pos_rank.resize(n);
+    t.rank_slot.resize(n);
+    t.root = e->chunk_root;
+    t.depth = e->chunk_depth;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(t.nodes.data(), e->chunk_nodes.ptr, sizeof(rb::ChunkNode) * t.nodes.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(t.pos_slot.data(), e->chunk_pos_slot.ptr, 4u * n, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(t.pos_rank.data(), e->chunk_pos_rank.ptr, 4u * n, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(t.rank_slot.data(), e->chunk_rank_slot.ptr, 4u * n, hipMemcpyDeviceToHost));
+    std::string why;
+    const uint32_t n_tris = std::min<uint32_t>(e->prep_tri_count, static_cast<uint32_t>(e->host_tris.size()));
+    if (!rb::chunk_tree_check(t, e->host_tris.data(), n_tris, e->host_indices.data(), static_cast<uint32_t>(e->host_indices.size()), rb::kStackDepth, why))
+        return fail(e, RB_ERR_INVALID_BVH, "chunk tree (%s builder): %s", e->chunk_builder, why.c_str());
+    chunk_tree_census(t, out6);
+    return RB_OK;
+}
+
+const char* rb_chunk_tree_builder(const rb_engine* e, float* build_ms) {
+    if (e && is_group(e)) e = e->parts[0].get();
+    if (build_ms) *build_ms = (e && e->chunk_ready) ? e->chunk_build_ms : 0.0f;
+    return (e && e->chunk_ready) ? e->chunk_builder : "";
 }
 
 int rb_measure_l1_gather(int32_t device, uint64_t table_bytes, double* accesses_per_s) {

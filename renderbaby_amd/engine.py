@@ -173,7 +173,7 @@ class Engine:
                  no_sphere_bvh=False, fast_bvh=False, lds_mode=0, device_bvh=False, no_leaf_stepping=False,
                  device_lbvh=False, reference_walk=False, host_bvh=False, devices=None, gather_peer_copy=False,
                  no_run_ahead=False, own_tree=False, skip_near_degenerate=False, queue_batch=0, chunk_walk=False,
-                 sphere_tree=None):
+                 sphere_tree=None, chunk_tree=None):
         """``devices`` (list of HIP ordinals): one handle over several devices of this process
         (rb_create_multi): rows sharded in stripes, one RCCL gather per delivered frame."""
         self._lib = load()
@@ -193,7 +193,8 @@ class Engine:
             | (abi.FLAG_HOST_BVH if host_bvh else 0) | (abi.FLAG_GATHER_PEER_COPY if gather_peer_copy else 0) \
             | (abi.FLAG_NO_RUN_AHEAD if no_run_ahead else 0) | (abi.FLAG_SKIP_NEAR_DEGENERATE if skip_near_degenerate else 0) \
             | (abi.FLAG_CHUNK_WALK if chunk_walk else 0) \
-            | {None: 0, "host": abi.FLAG_SPHERE_TREE_HOST, "device": abi.FLAG_SPHERE_TREE_DEVICE}[sphere_tree]
+            | {None: 0, "host": abi.FLAG_SPHERE_TREE_HOST, "device": abi.FLAG_SPHERE_TREE_DEVICE}[sphere_tree] \
+            | {None: 0, "host": abi.FLAG_CHUNK_TREE_HOST, "device": abi.FLAG_CHUNK_TREE_DEVICE}[chunk_tree]   # who builds the chunked walk's tree
         opt._reserved[0] = blocks_per_cu
         opt._reserved[1] = color_budget_mib
         opt._reserved[2] = queue_batch   # items a wave reserves per queue atomic (0 = the launcher's choice)
@@ -368,6 +369,20 @@ class Engine:
         ms = C.c_float()
         name = (self._lib.rb_sphere_tree_builder(self._h, C.byref(ms)) or b"").decode()
         return name, ms.value
+
+    def chunk_tree_builder(self):
+        """("device" | "host" | "", build milliseconds) of the chunked walk's tree (multi-node meshes, the default walk)."""
+        ms = C.c_float()
+        name = (self._lib.rb_chunk_tree_builder(self._h, C.byref(ms)) or b"").decode()
+        return name, ms.value
+
+    def debug_chunk_tree(self):
+        """The tree the engine walks, read back and checked (rb_debug_engine_chunk_tree): dict of its census, or None."""
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rb_debug_engine_chunk_tree(self._h, out))
+        if not out[0]:
+            return None
+        return dict(nodes=out[1], positions=out[2], depth=out[3], chunks=out[4], unbounded=out[5])
 
     def last_dispatch_ms(self):
         ms = C.c_float()

@@ -85,6 +85,8 @@ def test_entry_points_reject_a_null_engine_without_touching_the_gpu():
     assert (lib.rb_fast_bvh_builder(null, C.byref(ms)) or b"") == b"" and ms.value == 0.0
     assert (lib.rb_last_kernel_name(null) or b"") == b""
     assert (lib.rb_sphere_tree_builder(null, C.byref(ms)) or b"") == b"" and ms.value == 0.0
+    assert (lib.rb_chunk_tree_builder(null, C.byref(ms)) or b"") == b"" and ms.value == 0.0
+    assert lib.rb_debug_engine_chunk_tree(null, None) != 0
     assert lib.rb_reserve(null, 1) != 0
     assert lib.rb_debug_walk_profile(None, 0) != 0
     lib.rb_iter_destroy(null)

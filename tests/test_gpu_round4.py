@@ -1,7 +1,9 @@
 """Round-4 additions behind the boundary: the sphere tree from either builder (device: level-synchronous median splits,
 host: the same splits recursively) under every kernel that walks it, the pooled sphere kernel's tie rule and degenerate
-inputs, rb_reserve, the environment's reference-walk override, and the debug hook of the profiling build."""
+inputs, rb_reserve, the environment's reference-walk override, the debug hook of the profiling build, and the chunked walk's
+tree built on the device (one block per reference leaf) against the host builder's: same invariants, same census, same frames."""
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -111,3 +113,104 @@ def test_the_product_build_counts_no_passes():
     if os.environ.get("RB_LIBRARY_PATH"):
         pytest.skip("a variant library is loaded")
     assert _lib.load().rb_debug_walk_profile(out, 0) != 0   # only a profiling build (tools/walk_profile.sh) has counters
+
+
+# ---------------------------------------------------------------- the chunked walk's tree from the device builder
+def _chunk(scene, **kw):
+    rc = RenderConfig.from_scene(scene)
+    e = Engine.new(rc, **kw)
+    f = e.render(rc)
+    acc, name, builder, census = e.read_accumulation(), e.last_kernel_name(), e.chunk_tree_builder()[0], e.debug_chunk_tree()
+    e.close()
+    return f.pixels, acc, name, builder, census
+
+
+def _same_census(d, h):
+    # same split-off sets and the same split sizes, so the same shape: nodes, positions, depth and chunks agree exactly.  Which of
+    # several triangles with EQUAL centroids lands in which chunk is the sort's business (nth_element there, a bitonic network
+    # here), so the count of child slots whose margin is unbounded may differ by the few chunks a wall-sized triangle moved between
+    for k in ("nodes", "positions", "depth", "chunks"):
+        assert d[k] == h[k], (k, d, h)
+    assert abs(d["unbounded"] - h["unbounded"]) <= 0.1 * h["unbounded"] + 4, (d, h)
+
+
+def _with_tree(s, nodes, idx, **params):
+    s = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, nodes, idx, s.bvh_triangles, s.uvs)
+    return s.with_params(**params) if params else s
+
+
+@pytest.mark.parametrize("grid,size", [(6, 24), (24, 40), (70, 48)])
+def test_device_built_chunk_tree_equals_the_hosts_in_everything_that_matters(grid, size):
+    # 72 + ..., 1 152 + ..., 9 800 + ... triangles: forced onto the device builder (its default starts at 16 384 slots); the
+    # tree is read back and put through the host's invariant checker, its census compared with the host builder's
+    s = scenes.mesh_scene(grid, grid, size, size, 2, 5, seed=grid)
+    o_acc, _, o_rgba, _ = _oracle.render(s)
+    d_rgba, d_acc, name, builder, d_cen = _chunk(s, chunk_tree="device")
+    assert name == "k_trace_chunk" and builder == "device" and d_cen is not None
+    h_rgba, h_acc, name, builder, h_cen = _chunk(s, chunk_tree="host")
+    assert name == "k_trace_chunk" and builder == "host"
+    _same_census(d_cen, h_cen)
+    for acc, rgba in ((d_acc, d_rgba), (h_acc, h_rgba)):
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32))
+        assert np.array_equal(rgba, o_rgba)
+
+
+def test_device_chunk_tree_is_the_default_for_c3_and_splits_off_the_lamps_walls():
+    from renderbaby_amd import refscenes
+    for s, positions in ((scenes.mesh_c3().with_params(width=64, height=48, spp=1), 50178), (refscenes.ref_lamp(width=48, height=48, spp=1), 68768)):
+        d_rgba, d_acc, name, builder, d_cen = _chunk(s)
+        assert name == "k_trace_chunk" and builder == "device" and d_cen["positions"] == positions
+        h_rgba, h_acc, _, builder, h_cen = _chunk(s, chunk_tree="host")
+        assert builder == "host"
+        _same_census(d_cen, h_cen)
+        assert np.array_equal(d_acc.view(np.uint32), h_acc.view(np.uint32)) and np.array_equal(d_rgba, h_rgba)
+        assert 0 < d_cen["unbounded"] < d_cen["chunks"] / 3
+
+
+def test_device_chunk_tree_with_caller_made_trees_and_invalid_slots():
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    base = scenes.mesh_scene(20, 20, 40, 32, 2, 4, seed=31)
+    o_acc = _oracle.render(base)[0]
+    for max_leaf, lop, want in ((401, 0, "host"), (300, 0, "device"), (5, 0, "device"), (1, 0, "device"), (40, 4, "device")):   # leaves of 401 / 201 / 4 / 1 / 40 triangles
+        nodes, idx = gp._py_tree(base.bvh_triangles, max_leaf, lopsided=lop)
+        s = _with_tree(base, nodes, idx)
+        fat = int(nodes["primitive_count"].max())
+        rgba, acc, name, builder, cen = _chunk(s, chunk_tree="device")
+        # leaves beyond the 256 triangles a block holds go to the host builder, whatever was asked for
+        assert name == "k_trace_chunk" and builder == ("host" if fat > 256 else "device") and builder == want, (max_leaf, lop, fat, builder)
+        assert cen["positions"] == len(base.bvh_triangles)
+        assert np.array_equal(acc.view(np.uint32), _oracle.render(s)[0].view(np.uint32)), (max_leaf, lop)
+    # indices beyond the triangle count (guard shader.wgsl:336) and a leaf with nothing valid in it
+    nodes, idx = gp._py_tree(base.bvh_triangles, 16)
+    idx = idx.copy()
+    leaf = np.flatnonzero(nodes["primitive_count"] > 0)[3]
+    lo, cnt = int(nodes["first_primitive"][leaf]), int(nodes["primitive_count"][leaf])
+    idx[lo:lo + cnt] = 0xFFFFFFF0          # a whole leaf of invalid slots
+    idx[::7] = len(base.bvh_triangles) + 5  # and every seventh elsewhere
+    s = _with_tree(base, nodes, idx)
+    o_acc = _oracle.render(s)[0]
+    n_valid = int((idx < len(base.bvh_triangles)).sum())
+    for kw in (dict(chunk_tree="device"), dict(chunk_tree="host")):
+        rgba, acc, name, builder, cen = _chunk(s, **kw)
+        assert name == "k_trace_chunk" and builder == kw["chunk_tree"] and cen["positions"] == n_valid
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), kw
+
+
+def test_device_chunk_tree_of_degenerate_triangles():
+    # points, needles and repeated triangles: zero normals, zero bounds, equal sort keys everywhere
+    s = scenes.mesh_scene(12, 12, 32, 24, 2, 4, seed=5)
+    t = s.bvh_triangles.copy()
+    t["v1"][::3] = t["v0"][::3]            # needles (no normal)
+    t["v2"][::9] = t["v0"][::9]
+    t["v1"][::9] = t["v0"][::9]            # points
+    t[100:160] = t[100]                    # sixty copies of one triangle: t ties go to the lower rank
+    from renderbaby_amd import bvh
+    nodes, idx = bvh.build(t)
+    s = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, nodes, idx, t, s.uvs)
+    o_acc = _oracle.render(s)[0]
+    for kw in (dict(chunk_tree="device"), dict(chunk_tree="host")):
+        rgba, acc, name, builder, cen = _chunk(s, **kw)
+        assert name == "k_trace_chunk" and builder == kw["chunk_tree"] and cen is not None
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), kw

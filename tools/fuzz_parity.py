@@ -129,6 +129,7 @@ def variants(scene):
     if len(scene.bvh_nodes) > 1:
         v += [("stream-noLDS", dict(lds_mode=1, reference_walk=True)), ("stream-perseg", dict(no_leaf_stepping=True, reference_walk=True)),
               ("default", dict()), ("chunk-small-batches", dict(chunk_walk=True, queue_batch=64)),
+              ("chunk-device-tree", dict(chunk_tree="device")),   # the fuzzer's meshes are below the device builder's default threshold
               ("fast", dict(fast_bvh=True)),
               ("fast-device", dict(device_bvh=True)), ("fast-lbvh", dict(device_lbvh=True)), ("fast-queue", dict(fast_bvh=True, kernel=abi.KERNEL_QUEUE))]
     if len(scene.spheres) > 64:

@@ -62,6 +62,8 @@ def parse():
                     help="multi-node meshes: the reference walk or the library's own tree (default: the library's default)")
     ap.add_argument("--fast-bvh", action="store_true", help="same as --walk own-host")
     ap.add_argument("--device-bvh", action="store_true", help="same as --walk own-device")
+    ap.add_argument("--chunk-tree", default=None, choices=["host", "device"],
+                    help="who builds the chunked walk's tree (default: the library's choice -- the device from 16 384 triangle slots up)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --same-device) rehearses the N>1 path on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -211,6 +213,7 @@ def end_to_end(scene, wkw, kernel, device):
     eng.dispatch(0, 0)                       # prepared triangles + the library's own levels of the tree, nothing traced
     eng.sync()
     out["tree_build_ms"] = (time.perf_counter() - t) * 1e3
+    out["chunk_tree"], out["chunk_tree_build_ms"] = eng.chunk_tree_builder()      # (inside tree_build_ms; "" = another walk)
     out["sphere_tree"], out["sphere_tree_build_ms"] = eng.sphere_tree_builder()   # (inside upload_ms: rb_update builds it)
     t = time.perf_counter()
     eng.reserve(scene.total_samples)         # the stream kernels' colour buffer (lazily allocated otherwise: up to 4 GiB of hipMalloc)
@@ -297,7 +300,7 @@ def main():
 
     scene, desc = make_scene(a.workload, a.spp)
     spp = scene.total_samples
-    wkw = dict(walk_kwargs(a.walk), skip_near_degenerate=a.skip_near_degenerate)
+    wkw = dict(walk_kwargs(a.walk), skip_near_degenerate=a.skip_near_degenerate, chunk_tree=a.chunk_tree)
 
     def barrier():
         if world > 1:

@@ -145,8 +145,13 @@ struct rb_engine {
     uint32_t chunk_root = 0, chunk_depth = 0;
     bool chunk_ready = false;
     float chunk_build_ms = 0.0f;
-    std::vector<rb_gpu_triangle> host_tris;  // kept while the library's own tree may be (re)built
+    // The host's copy of the mesh, for the host builders and the checkers.  A large mesh (>= kChunkDeviceBuildMin elements: the
+    // device builder's territory) is NOT copied at rb_update -- a second 88 MB in host memory cost C5's update 10 of its 14 ms --
+    // but fetched back from the device buffer if a host builder turns out to be needed after all (ensure_host_mesh).
+    std::vector<rb_gpu_triangle> host_tris;
     std::vector<uint32_t> host_indices;
+    size_t host_tri_len = 0, host_index_len = 0;   // what the vectors hold, or would hold (0: the engine keeps no copy)
+    bool host_tris_stale = false, host_indices_stale = false;
     DevBuf<rb::SphereNode4> sph_nodes;  // own sphere acceleration structure (n_spheres > threshold)
     DevBuf<float> sph_leaf;
     DevBuf<uint32_t> sph_id;
@@ -423,6 +428,11 @@ Act field_action(int idx, const rb_field& f, bool first) {
 
 // may the library's own tree be wanted for this engine's meshes?  (host copies of triangles / indices are kept then)
 bool may_want_own_tree(const rb_engine* e) { return !(e->opt.flags & RB_FLAG_REFERENCE_WALK); }
+// a mesh of `n` elements whose host copy can wait (ensure_host_mesh): large enough for the device builder, and no flag that
+// sends the build to a host builder anyway
+bool host_copy_can_wait(const rb_engine* e, size_t n) {
+    return n >= rb::kChunkDeviceBuildMin && !(e->opt.flags & (RB_FLAG_CHUNK_TREE_HOST | RB_FLAG_FAST_BVH | RB_FLAG_HOST_BVH | RB_FLAG_DEVICE_BVH));
+}
 // is it wanted for a mesh of n_tris triangles?
 bool wants_own_tree(const rb_engine* e, uint32_t n_tris) {   // (asked only when the chunked walk is not in use)
     if (e->opt.flags & RB_FLAG_REFERENCE_WALK) return false;
@@ -474,13 +484,23 @@ int apply_field(rb_engine* e, int idx, const rb_field& f, bool first) {
         case 6:
             rc = upload(e, e->indices, src, n, &e->n_indices, true);
             e->prep_dirty = true;
-            if (may_want_own_tree(e)) e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
+            if (may_want_own_tree(e)) {
+                e->host_index_len = n;
+                e->host_indices_stale = host_copy_can_wait(e, n);
+                if (e->host_indices_stale) std::vector<uint32_t>().swap(e->host_indices);
+                else e->host_indices.assign(static_cast<const uint32_t*>(src), static_cast<const uint32_t*>(src) + n);
+            }
             break;
         case 7:
             rc = upload(e, e->tris, src, n, nullptr, true);
             e->n_tris = static_cast<uint32_t>(n);
             e->prep_dirty = true;
-            if (may_want_own_tree(e)) e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
+            if (may_want_own_tree(e)) {
+                e->host_tri_len = n;
+                e->host_tris_stale = host_copy_can_wait(e, n);
+                if (e->host_tris_stale) std::vector<rb_gpu_triangle>().swap(e->host_tris);
+                else e->host_tris.assign(static_cast<const rb_gpu_triangle*>(src), static_cast<const rb_gpu_triangle*>(src) + n);
+            }
             break;
         case 8:
             if (del) { rb_field empty{RB_UPDATE, nullptr, 0}; rc = upload_textures(e, empty); }
@@ -577,6 +597,25 @@ uint32_t patch_count(uint32_t change, uint32_t given, uint32_t len) {
     return std::min(given, len);
 }
 
+// The host builders and checkers read host_tris / host_indices: bring back what rb_update left on the device only.
+int ensure_host_mesh(rb_engine* e) {
+    if (!e->host_tris_stale && !e->host_indices_stale) return RB_OK;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->host_tris_stale) {
+        if (e->host_tri_len > e->tris.count) return fail(e, RB_ERR_DEVICE, "the triangle buffer is shorter than the mesh it was made from");
+        e->host_tris.resize(e->host_tri_len);
+        HIP_TRY(e, hipMemcpy(e->host_tris.data(), e->tris.ptr, sizeof(rb_gpu_triangle) * e->host_tri_len, hipMemcpyDeviceToHost));
+        e->host_tris_stale = false;
+    }
+    if (e->host_indices_stale) {
+        if (e->host_index_len > e->indices.count) return fail(e, RB_ERR_DEVICE, "the index buffer is shorter than the mesh it was made from");
+        e->host_indices.resize(e->host_index_len);
+        HIP_TRY(e, hipMemcpy(e->host_indices.data(), e->indices.ptr, 4u * e->host_index_len, hipMemcpyDeviceToHost));
+        e->host_indices_stale = false;
+    }
+    return RB_OK;
+}
+
 int ensure_prepared(rb_engine* e) {
     // shader.wgsl:336 skips triangle ids >= uniforms.bvh_triangle_count: the prepared triangles carry that
     // guard as their `valid` word, so they depend on the (patched) count as well as on the buffers
@@ -592,10 +631,10 @@ int ensure_prepared(rb_engine* e) {
     // ---- the chunked walk's tree: the caller's tree with the library's own levels below its leaves
     e->chunk_ready = false;
     e->fast_ready = false;
-    if (wants_chunk_walk(e) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+    if (wants_chunk_walk(e) && e->host_nodes.size() > 1 && e->host_tri_len > 0 && e->host_index_len > 0 && tri_count > 0) {
         const auto t_begin = std::chrono::steady_clock::now();
-        const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tris.size()));
-        const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size()), n_nodes = static_cast<uint32_t>(e->host_nodes.size());
+        const uint32_t n_tris = std::min<uint32_t>(tri_count, static_cast<uint32_t>(e->host_tri_len));
+        const uint32_t n_idx = static_cast<uint32_t>(e->host_index_len), n_nodes = static_cast<uint32_t>(e->host_nodes.size());
         // which builder: the device one from kChunkDeviceBuildMin slots up (one block per reference leaf; C5's 10^6 triangles
         // in a few ms where the host's threads take 11-15), the host's below; either can be forced.  Same walk, same frames.
         const bool force_host = (e->opt.flags & RB_FLAG_CHUNK_TREE_HOST) != 0u, force_dev = (e->opt.flags & RB_FLAG_CHUNK_TREE_DEVICE) != 0u;
@@ -621,6 +660,8 @@ int ensure_prepared(rb_engine* e) {
         }
         if (!built) {
             rb::ChunkTree ct;
+            rc = ensure_host_mesh(e);
+            if (rc) return rc;
             if (rb::chunk_tree_build(e->host_tris.data(), n_tris, e->host_indices.data(), n_idx, e->host_nodes.data(), n_nodes, rb::kStackDepth, ct)) {
                 n = ct.pos_slot.size();
                 rc = upload(e, e->chunk_nodes, ct.nodes.data(), ct.nodes.size(), nullptr, true);
@@ -649,7 +690,9 @@ int ensure_prepared(rb_engine* e) {
         }
     }
     // ---- the library's own tree over the same triangles
-    if (!e->chunk_ready && wants_own_tree(e, tri_count) && e->host_nodes.size() > 1 && !e->host_tris.empty() && !e->host_indices.empty() && tri_count > 0) {
+    if (!e->chunk_ready && wants_own_tree(e, tri_count) && e->host_nodes.size() > 1 && e->host_tri_len > 0 && e->host_index_len > 0 && tri_count > 0) {
+        rc = ensure_host_mesh(e);
+        if (rc) return rc;
         rb::FastTree ft;
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n_idx = static_cast<uint32_t>(e->host_indices.size());
@@ -1893,6 +1936,10 @@ int rb_debug_engine_chunk_tree(rb_engine* e, uint64_t out6[6]) {
     HIP_TRY(e, hipMemcpy(t.pos_rank.data(), e->chunk_pos_rank.ptr, 4u * n, hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(t.rank_slot.data(), e->chunk_rank_slot.ptr, 4u * n, hipMemcpyDeviceToHost));
     std::string why;
+    {
+        const int hrc = ensure_host_mesh(e);
+        if (hrc) return hrc;
+    }
     const uint32_t n_tris = std::min<uint32_t>(e->prep_tri_count, static_cast<uint32_t>(e->host_tris.size()));
     if (!rb::chunk_tree_check(t, e->host_tris.data(), n_tris, e->host_indices.data(), static_cast<uint32_t>(e->host_indices.size()), rb::kStackDepth, why))
         return fail(e, RB_ERR_INVALID_BVH, "chunk tree (%s builder): %s", e->chunk_builder, why.c_str());

@@ -214,3 +214,20 @@ def test_device_chunk_tree_of_degenerate_triangles():
         rgba, acc, name, builder, cen = _chunk(s, **kw)
         assert name == "k_trace_chunk" and builder == kw["chunk_tree"] and cen is not None
         assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)), kw
+
+
+def test_large_mesh_whose_leaves_the_device_builder_declines_is_fetched_back_for_the_host_builder():
+    # from 16 384 elements up rb_update keeps no host copy of the mesh (the device builder needs none); a caller's tree with
+    # leaves of more than 256 triangles still goes to the host builder, which then reads the mesh back from the device
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    s = scenes.mesh_c3().with_params(width=48, height=32, spp=1)
+    nodes, idx = gp._py_tree(s.bvh_triangles, 1000)
+    assert int(nodes["primitive_count"].max()) > 256
+    s = _with_tree(s, nodes, idx)
+    rgba, acc, name, builder, cen = _chunk(s)
+    assert name == "k_trace_chunk" and builder == "host" and cen["positions"] == 50178
+    r_rgba, r_acc, r_name, _, r_cen = _chunk(s, reference_walk=True)
+    assert r_name.startswith("k_trace_bvh") and r_cen is None
+    assert np.array_equal(acc.view(np.uint32), r_acc.view(np.uint32)) and np.array_equal(rgba, r_rgba)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from renderbaby_amd import Engine, RenderConfig, _lib, abi, scenes
+from renderbaby_amd.engine import Change
 from tests import _oracle
 
 pytestmark = pytest.mark.gpu
@@ -231,3 +232,51 @@ def test_large_mesh_whose_leaves_the_device_builder_declines_is_fetched_back_for
     r_rgba, r_acc, r_name, _, r_cen = _chunk(s, reference_walk=True)
     assert r_name.startswith("k_trace_bvh") and r_cen is None
     assert np.array_equal(acc.view(np.uint32), r_acc.view(np.uint32)) and np.array_equal(rgba, r_rgba)
+
+
+def test_updates_of_a_large_mesh_rebuild_the_device_tree_from_what_is_on_the_device():
+    # 50 178 triangles: rb_update keeps no host copy, the device builder makes the tree.  Triangles, count, tree and indices are then
+    # changed one at a time on the SAME engine; after every change the frame must be the one a fresh reference-walk engine
+    # renders of the scene as it now stands, and the tree read back must pass the checker
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    s = scenes.mesh_c3().with_params(width=48, height=32, spp=1)
+
+    def reference(scene):
+        rc = RenderConfig.from_scene(scene)
+        e = Engine.new(rc, reference_walk=True)
+        e.render(rc)
+        a = e.read_accumulation()
+        e.close()
+        return a
+
+    rc = RenderConfig.from_scene(s)
+    e = Engine.new(rc)
+    e.render(rc)
+    assert e.chunk_tree_builder()[0] == "device" and e.debug_chunk_tree()["positions"] == 50178
+    assert np.array_equal(e.read_accumulation().view(np.uint32), reference(s).view(np.uint32))
+    # (1) new triangles, tree and indices kept (the boxes no longer fit all of them: such children are always entered)
+    t = s.bvh_triangles.copy()
+    rng = np.random.default_rng(9)
+    for k in ("v0", "v1", "v2"):
+        t[k] += rng.uniform(-0.05, 0.05, t[k].shape).astype(np.float32)
+    s1 = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, s.bvh_nodes, s.bvh_indices, t, s.uvs)
+    e.render(RenderConfig(uniforms=Change.update(s.uniforms), bvh_triangles=Change.update(t)))   # (a render needs uniforms in its update: gpu_wrapper.rs:313)
+    assert e.chunk_tree_builder()[0] == "device" and e.debug_chunk_tree()["positions"] == 50178
+    assert np.array_equal(e.read_accumulation().view(np.uint32), reference(s1).view(np.uint32))
+    # (2) a caller's tree with leaves the device builder declines: the host builder fetches the NEW triangles back
+    nodes, idx = gp._py_tree(t, 1000)
+    s2 = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, nodes, idx, t, s.uvs)
+    e.render(RenderConfig(uniforms=Change.update(s.uniforms), bvh_nodes=Change.update(nodes), bvh_indices=Change.update(idx)))
+    assert e.chunk_tree_builder()[0] == "host" and e.debug_chunk_tree()["positions"] == 50178
+    assert np.array_equal(e.read_accumulation().view(np.uint32), reference(s2).view(np.uint32))
+    # (3) back to a tree of small leaves with a seventh of the indices invalid: the device builder again
+    nodes, idx = gp._py_tree(t, 64)
+    idx = idx.copy()
+    idx[::7] = len(t) + 3
+    s3 = scenes.Scene(s.uniforms, s.spheres, s.lights, s.meshes, nodes, idx, t, s.uvs)
+    e.render(RenderConfig(uniforms=Change.update(s.uniforms), bvh_nodes=Change.update(nodes), bvh_indices=Change.update(idx)))
+    assert e.chunk_tree_builder()[0] == "device" and e.debug_chunk_tree()["positions"] == int((idx < len(t)).sum())
+    assert np.array_equal(e.read_accumulation().view(np.uint32), reference(s3).view(np.uint32))
+    e.close()
